@@ -1,0 +1,127 @@
+/*
+ * gigl_oracle.h — C interface of the CPU ORACLE (test infrastructure, NOT product).
+ *
+ * This is a CPU restatement of the reference's ray-query path (zero-radiance/GIGL,
+ * Source/RT + Source/Common/BBox + Source/Fog sampling), written from the reference's
+ * published algorithm with no GLM and no reference source text.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it, and only as the
+ * checker.  The product library (gigl_amd/lib/libgigl_rt.so) never links or calls it.
+ *
+ * Pinning: the reference cannot be built in this image without stand-ins for OpenGL,
+ * Win32 and the MSVC CRT (see DESIGN.md "Oracle"), so no oracle/_ref exists.  The
+ * restatement is pinned against the outputs of the reference recorded when it was run
+ * in this container at survey time (tests/golden/survey_facts.json).
+ * Sub-paths those facts do not cover are marked "parity unpinned" at their definition.
+ *
+ * All citations are path:line under /root/reference.
+ */
+#ifndef GIGL_ORACLE_H
+#define GIGL_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ora_scene ora_scene;
+
+/* Source/RT/KdTree.hpp:87-132 (constructor) + :139-264 (buildTree).
+ * verts: float[3*n_verts]; tris: uint32[4*n_tris] = (i0,i1,i2,mat_id) per triangle. */
+ora_scene* ora_scene_create(const float* verts, uint32_t n_verts, const uint32_t* tris,
+                            uint32_t n_tris, int inters_cost, int trav_cost, int max_depth,
+                            uint32_t min_num_prims, float empty_bonus);
+void ora_scene_destroy(ora_scene* s);
+
+/* Statistics the reference prints (Source/RT/KdTree.hpp:126-131). */
+uint32_t ora_scene_n_nodes(const ora_scene* s);
+uint32_t ora_scene_n_leaf_prim_ids(const ora_scene* s);
+int      ora_scene_depth(const ora_scene* s);
+uint32_t ora_scene_leaf_count(const ora_scene* s);
+float    ora_scene_avg_prims_per_leaf(const ora_scene* s);
+/* Source/RT/KdTree.hpp:135-137; out = min xyz, max xyz. */
+void     ora_scene_bbox(const ora_scene* s, float out[6]);
+/* Raw tree in the reference's own 8-byte node encoding (Source/RT/KdTree.h:22-65):
+ * word0 = split_pos bits | single_prim_id | prims_offset; word1 bit0 = is_leaf,
+ * interior: bits1-2 axis, bits3-31 above_child; leaf: bits1-31 n_prims. */
+void     ora_scene_copy_nodes(const ora_scene* s, uint32_t* out_words /* 2*n_nodes */);
+void     ora_scene_copy_leaf_prim_ids(const ora_scene* s, uint32_t* out);
+
+/* Source/RT/RTBase.h:18-29 */
+float ora_rescaled_eps(float t);
+
+/* Source/Common/BBox.cpp:81-109.  box = min xyz, max xyz.  Returns 1 on hit. */
+int ora_bbox_intersect(const float box[6], const float o[3], const float d[3], float t_min,
+                       float t_max, float* entr, float* exit);
+
+/* Scene::trace (Source/Common/Scene.cpp:234-243) over a batch of FRESH rays
+ * (Ray ctor: Source/RT/RTBase.cpp:111-115, then setValidRange(tmin,tmax)).
+ * rays_o_tmin / rays_d_tmax: float[4*n] = (ox,oy,oz,tmin) / (dx,dy,dz,tmax).
+ * Closest mode writes hits: uint32 tri_id (0xFFFFFFFF miss) + float t,u,v  (16 B/ray).
+ * counters (optional, may be NULL): uint32[2*n] = nodes_visited, triangle_tests per ray.
+ * n_threads <= 1: serial; otherwise OpenMP schedule(dynamic). */
+void ora_trace_closest(const ora_scene* s, const float* rays_o_tmin, const float* rays_d_tmax,
+                       uint64_t n, void* hits16, uint32_t* counters, int n_threads);
+/* is_vis_ray = true (Source/RT/KdTree.hpp:267,328).  occluded: uint8[n] (0/1). */
+void ora_trace_any(const ora_scene* s, const float* rays_o_tmin, const float* rays_d_tmax,
+                   uint64_t n, uint8_t* occluded, uint32_t* counters, int n_threads);
+
+/* PerspectiveCamera ctor + getPrimaryRay (Source/Common/Camera.cpp:15-33, :65-68).
+ * cam_out: float[12] = pos, bottom_left, step_x, step_y. */
+void ora_camera_setup(const float pos[3], const float dir[3], const float up[3], float h_fov,
+                      int res_x, int res_y, float cam_out[12]);
+/* Rays for pixels [first, first+n) in row-major order, centre (x+0.5, y+0.5)
+ * (Source/Fog/DensityField.cpp:288). */
+void ora_primary_rays(const float cam[12], int res_x, uint64_t first, uint64_t n,
+                      float* rays_o_tmin, float* rays_d_tmax);
+
+/* Shadow-ray construction (the build's definition, SURVEY.md Appendix A "Shadow-ray
+ * convention"; DESIGN.md "Shadow batch").  Per (point p, light l):
+ *   p = o + t*d of the primary hit, N = normalize(cross(e0,e1)) flipped to face -d,
+ *   L = light position, dirv = L - p, dist = length(dirv),
+ *   ray = Ray{p, normalize(dirv), N} (origin lifted by RAY_OFFSET*N), range (0, dist).
+ * prim_hits16: closest-hit records of the primary rays; points with a miss emit no rays and
+ * their occlusion bytes are 0xFF.  lights: float[3*n_lights]. occluded: uint8[n_pts*n_lights].
+ * transm (optional): float[n_pts*n_lights] = calcTransm of the same segment (see below),
+ * written for every pair with a primary hit (1.0 otherwise). */
+typedef struct ora_fog {
+    const uint8_t* dens;   /* res[0]*res[1]*res[2] bytes, x fastest (DensityField.cpp:59) */
+    int   res[3];
+    float box[6];          /* min xyz, max xyz */
+    float ext_k;           /* abs_k + sca_k (Source/Fog/FogVolume.cpp:34) */
+    int   n_intervals;     /* R_M_INTERVALS = 8 */
+} ora_fog;
+void ora_shadow_batch(const ora_scene* s, const float* prim_o_tmin, const float* prim_d_tmax,
+                      const void* prim_hits16, uint64_t n_pts, const float* lights,
+                      uint32_t n_lights, uint8_t* occluded, const ora_fog* fog, float* transm,
+                      int n_threads);
+
+/* DensityField::sampleDensity (Source/Fog/DensityField.cpp:177-211). */
+float ora_sample_density(const ora_fog* fog, const float pos[3]);
+/* calcTransm + intersectBBox + rayMarch (Source/Shaders/Surface.frag:139-203) with
+ * sampleDensity's software trilinear filter standing in for texture().  PARITY UNPINNED:
+ * GLSL cannot run here and no reference output exists for it.
+ * segs: float[8*n] = (px,py,pz,_, dx,dy,dz,dist_sq). */
+void ora_transmittance(const ora_fog* fog, const float* seg_p, const float* seg_d_distsq,
+                       uint64_t n, float* transm, int n_threads);
+
+/* DensityField noise constructor (Source/Fog/DensityField.cpp:18-76) with GLM 0.9.5.4's
+ * simplex(vec3) (Source/Include/GLM/gtc/noise.inl:679-751).  out: res^3 bytes. */
+void ora_make_density(const int res[3], float freq, float ampl, uint8_t* out);
+
+/* PhotonTracer::trace (Source/RT/PhotonTracer.cpp:78-188) with the RNG as an explicit
+ * float stream.  PARITY UNPINNED (no recorded VPL set).  materials: float[12*n_mat] =
+ * k_d(3) pad k_s(3) n_s k_e(3) pad (Source/RT/RTBase.h:72-77).  vpls_out: 96 B records
+ * (Source/VPL/PointLight.h:66-77).  Returns number of VPLs (0 on failure); *n_paths_out,
+ * *n_rng_used_out report the walk. */
+int ora_photon_trace(const ora_scene* s, const float* materials, uint32_t n_mat,
+                     const ora_fog* fog, float abs_k, float sca_k, float maj_ext_k,
+                     int fog_enabled, const float ppl_pos[3], const float ppl_intens[3],
+                     const float shoot_dir[3], int max_vpl_count, const float* rng,
+                     uint64_t n_rng, void* vpls_out, uint32_t* n_paths_out,
+                     uint64_t* n_rng_used_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
