@@ -1,0 +1,1094 @@
+// gigl_rt.hip — HIP kernels (gfx950) and C-ABI implementation of the ray-query engine.
+//
+// Device arithmetic restates, operation for operation, the reference's scalar float code:
+//   BBox::intersect        /root/reference/Source/Common/BBox.cpp:81-109
+//   getRescaledEPS         Source/RT/RTBase.h:18-29
+//   KdTree::intersect      Source/RT/KdTree.hpp:266-347
+//   Triangle::intersect    Source/RT/RTBase.cpp:150-177
+//   Scene::trace           Source/Common/Scene.cpp:234-243
+//   getPrimaryRay          Source/Common/Camera.cpp:65-68
+//   sampleDensity          Source/Fog/DensityField.cpp:177-211
+//   calcTransm / rayMarch  Source/Shaders/Surface.frag:139-203
+// Build flags that are part of the contract: -ffp-contract=off (no FMA fusion; the reference is
+// MSVC /fp:precise), correctly rounded f32 divide and sqrt (hipcc default), f32 denormals kept.
+// min/max are written as selects (GLM func_common.inl:377,395), never fminf/fmaxf.
+//
+// Execution model: persistent wavefronts.  Each 64-lane wave pulls ray indices from a global
+// counter, one ray per lane, and refills idle lanes (found with a ballot) once enough of them
+// have retired, so long-tailed rays do not hold 63 idle lanes hostage.  The per-lane traversal
+// stack holds (t_split, node) pairs — t_min/t_max are rebuilt from them on pop, see pop_stack() —
+// with the first STACK_N entries in LDS (lane-interleaved, conflict-free ds_read/write_b64) and
+// the rare deeper entries in a global spill area.
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/gigl_rt.h"
+#include "kd_build.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------
+constexpr float kEPS = 1.1920928955078125e-07f;  // std::numeric_limits<float>::epsilon(), RTBase.h:12
+constexpr float kRayOffset = 1E-4f;              // Source/Common/Constants.h:24
+constexpr float kTriEps = 1E-4f;                 // Constants.h:25
+constexpr unsigned kMiss = 0xFFFFFFFFu;
+
+__device__ __forceinline__ float gmin(float x, float y) { return x < y ? x : y; }
+__device__ __forceinline__ float gmax(float x, float y) { return x > y ? x : y; }
+__device__ __forceinline__ float sel3(unsigned a, float x, float y, float z) { return a == 0u ? x : (a == 1u ? y : z); }
+
+// RTBase.h:18-29.  frexp's exponent comes from v_frexp_exp_i32_f32 (0 for 0/inf/nan, as glibc);
+// `1 << exp` is evaluated with the count masked to 5 bits, as x86 shl does for the reference.
+__device__ __forceinline__ float rescaled_eps(float t) {
+    int e = __builtin_amdgcn_frexp_expf(t);
+    ++e;
+    if (e >= 0) return kEPS * (float)(int)(1u << ((unsigned)e & 31u));
+    return kEPS / (float)(int)(1u << ((unsigned)(-e) & 31u));
+}
+
+struct RayReg {
+    float ox, oy, oz, dx, dy, dz, ix, iy, iz, tmin, tmax;
+};
+
+__device__ __forceinline__ void set_dir(RayReg& r, float dx, float dy, float dz) {
+    r.dx = dx; r.dy = dy; r.dz = dz;
+    r.ix = 1.0f / dx; r.iy = 1.0f / dy; r.iz = 1.0f / dz;  // Ray ctor, RTBase.cpp:111-113
+}
+
+struct BoxF { float mnx, mny, mnz, mxx, mxy, mxz; };
+
+// BBox.cpp:81-109
+__device__ __forceinline__ bool box_intersect(const BoxF& b, const RayReg& r, float& entr, float& exit) {
+    const bool sx = r.ix >= 0.0f, sy = r.iy >= 0.0f, sz = r.iz >= 0.0f;
+    float t_entr = ((sx ? b.mnx : b.mxx) - r.ox) * r.ix;
+    float t_exit = ((sx ? b.mxx : b.mnx) - r.ox) * r.ix;
+    const float t_y_min = ((sy ? b.mny : b.mxy) - r.oy) * r.iy;
+    const float t_y_max = ((sy ? b.mxy : b.mny) - r.oy) * r.iy;
+    if ((t_entr > t_y_max) || (t_y_min > t_exit)) return false;
+    t_entr = gmax(t_entr, t_y_min);
+    t_exit = gmin(t_exit, t_y_max);
+    const float t_z_min = ((sz ? b.mnz : b.mxz) - r.oz) * r.iz;
+    const float t_z_max = ((sz ? b.mxz : b.mnz) - r.oz) * r.iz;
+    if ((t_entr > t_z_max) || (t_z_min > t_exit)) return false;
+    t_entr = gmax(t_entr, t_z_min);
+    t_exit = gmin(t_exit, t_z_max);
+    if (t_entr < r.tmax && t_exit > r.tmin) {
+        entr = t_entr; exit = t_exit;
+        return t_entr < FLT_MAX;  // IntDist::operator bool, BBox.cpp:13-15
+    }
+    return false;
+}
+
+struct TraceParams {
+    const uint2* nodes;
+    const unsigned* leaf_ids;
+    const float4* tris;   // 3 float4 per triangle: (p0.xyz,e0.x) (e0.yz,e1.xy) (e1.z,-,-,-)
+    BoxF box;
+    unsigned n;
+    unsigned* counter;
+    uint2* spill;
+    unsigned spill_stride;
+    int refill_thresh;
+    int any_atomic;
+    // GEN 0: explicit rays
+    const float4* o_tmin;
+    const float4* d_tmax;
+    // GEN 1: primary rays
+    float cam[12];
+    unsigned res_x, first;
+    // GEN 2: shadow pairs
+    const float4* prim_o;
+    const float4* prim_d;
+    const uint4* prim_hits;
+    const float* lights;
+    unsigned n_lights;
+    // outputs
+    uint4* hits;
+    unsigned long long* bits;
+};
+
+// getPrimaryRay(x + 0.5, y + 0.5), Camera.cpp:65-68; normalize = v * (1/sqrt(dot)) (GLM).
+__device__ __forceinline__ void primary_ray(const float* cam, unsigned res_x, unsigned pix, float& dx, float& dy,
+                                            float& dz) {
+    const float x = (float)(int)(pix % res_x) + 0.5f, y = (float)(int)(pix / res_x) + 0.5f;
+    const float vx = (cam[3] + x * cam[6]) + y * cam[9];
+    const float vy = (cam[4] + x * cam[7]) + y * cam[10];
+    const float vz = (cam[5] + x * cam[8]) + y * cam[11];
+    const float sqr = vx * vx + vy * vy + vz * vz;
+    const float inv = 1.0f / sqrtf(sqr);
+    dx = vx * inv; dy = vy * inv; dz = vz * inv;
+}
+
+struct ShadowSeg { float px, py, pz, wx, wy, wz, dist_sq, dist; float nx, ny, nz; };
+
+// Shadow-ray construction (DESIGN.md "Shadow batch"): p = o + t*d; N = normalize(cross(e0,e1))
+// turned to face the primary ray; w = normalize(L - p); range (0, |L - p|).
+__device__ __forceinline__ bool shadow_segment(const TraceParams& P, unsigned pair, ShadowSeg& s) {
+    const unsigned pt = pair / P.n_lights, l = pair - pt * P.n_lights;
+    const uint4 h = P.prim_hits[pt];
+    if (h.x == kMiss) return false;
+    const float4 o = P.prim_o[pt], d = P.prim_d[pt];
+    const float t = __uint_as_float(h.y);
+    s.px = o.x + t * d.x; s.py = o.y + t * d.y; s.pz = o.z + t * d.z;  // getPtAtDist, RTBase.cpp:124-126
+    const float4 a = P.tris[3 * (size_t)h.x], b = P.tris[3 * (size_t)h.x + 1];
+    const float e1z = P.tris[3 * (size_t)h.x + 2].x;
+    const float e0x = a.w, e0y = b.x, e0z = b.y, e1x = b.z, e1y = b.w;
+    float nx = e0y * e1z - e1y * e0z, ny = e0z * e1x - e1z * e0x, nz = e0x * e1y - e1x * e0y;
+    const float inv = 1.0f / sqrtf(nx * nx + ny * ny + nz * nz);
+    nx = nx * inv; ny = ny * inv; nz = nz * inv;
+    if ((d.x * nx + d.y * ny) + d.z * nz > 0.0f) { nx = -nx; ny = -ny; nz = -nz; }
+    s.nx = nx; s.ny = ny; s.nz = nz;
+    const float vx = P.lights[3 * l] - s.px, vy = P.lights[3 * l + 1] - s.py, vz = P.lights[3 * l + 2] - s.pz;
+    s.dist_sq = (vx * vx + vy * vy) + vz * vz;
+    s.dist = sqrtf(s.dist_sq);
+    const float iv = 1.0f / sqrtf(s.dist_sq);
+    s.wx = vx * iv; s.wy = vy * iv; s.wz = vz * iv;
+    return true;
+}
+
+template <int GEN>
+__device__ __forceinline__ bool fetch_ray(const TraceParams& P, unsigned idx, RayReg& r) {
+    if (GEN == 0) {
+        const float4 o = P.o_tmin[idx], d = P.d_tmax[idx];
+        r.ox = o.x; r.oy = o.y; r.oz = o.z;
+        set_dir(r, d.x, d.y, d.z);
+        r.tmin = o.w; r.tmax = d.w;
+        return true;
+    } else if (GEN == 1) {
+        float dx, dy, dz;
+        primary_ray(P.cam, P.res_x, P.first + idx, dx, dy, dz);
+        r.ox = P.cam[0]; r.oy = P.cam[1]; r.oz = P.cam[2];
+        set_dir(r, dx, dy, dz);
+        r.tmin = 0.0f; r.tmax = FLT_MAX;
+        return true;
+    } else {
+        ShadowSeg s;
+        if (!shadow_segment(P, idx, s)) return false;
+        r.ox = s.px + kRayOffset * s.nx; r.oy = s.py + kRayOffset * s.ny; r.oz = s.pz + kRayOffset * s.nz;
+        set_dir(r, s.wx, s.wy, s.wz);
+        r.tmin = 0.0f; r.tmax = s.dist;
+        return true;
+    }
+}
+
+// Triangle::intersect, RTBase.cpp:150-177.  Edges are stored precomputed (pt1-pt0, pt2-pt0 are
+// the same float subtractions the reference performs per test).
+__device__ __forceinline__ bool tri_test(const float4* __restrict__ tris, unsigned id, const RayReg& r,
+                                         float& best_t, float& best_u, float& best_v, unsigned& best_id) {
+    const float4 a = tris[3 * (size_t)id], b = tris[3 * (size_t)id + 1];
+    const float e1z = tris[3 * (size_t)id + 2].x;
+    const float p0x = a.x, p0y = a.y, p0z = a.z, e0x = a.w, e0y = b.x, e0z = b.y, e1x = b.z, e1y = b.w;
+    const float pvx = r.dy * e1z - e1y * r.dz, pvy = r.dz * e1x - e1z * r.dx, pvz = r.dx * e1y - e1x * r.dy;
+    const float det = (e0x * pvx + e0y * pvy) + e0z * pvz;
+    if (det != 0.0f) {
+        const float inv_det = 1.0f / det;
+        const float tx = r.ox - p0x, ty = r.oy - p0y, tz = r.oz - p0z;
+        const float qx = ty * e0z - e0y * tz, qy = tz * e0x - e0z * tx, qz = tx * e0y - e0x * ty;
+        const float u = ((tx * pvx + ty * pvy) + tz * pvz) * inv_det;
+        const float v = ((r.dx * qx + r.dy * qy) + r.dz * qz) * inv_det;
+        if (u >= -kTriEps && v >= -kTriEps && (u + v) <= 1.0f + 2.0f * kTriEps) {
+            const float dist = ((e1x * qx + e1y * qy) + e1z * qz) * inv_det;
+            if (r.tmin < dist && dist < r.tmax && dist < best_t) {
+                best_t = dist; best_u = u; best_v = v; best_id = id;
+                return true;
+            }
+        }
+    }
+    return false;
+}
+
+template <bool ANY, int GEN, int STACK_N, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
+    __shared__ uint2 s_stack[STACK_N * BLOCK];
+    const unsigned tid = threadIdx.x;
+    const unsigned lane = tid & 63u;
+    uint2* const my_stack = s_stack + tid;
+    uint2* const my_spill = P.spill + ((size_t)blockIdx.x * BLOCK + tid);
+
+    RayReg r;
+    float root_tmax = 0.0f;
+    float best_t = FLT_MAX, best_u = 0.0f, best_v = 0.0f;
+    unsigned best_id = kMiss;
+    unsigned node = 0, ray_idx = 0;
+    int sp = -1;
+    bool have_ray = false, pool_empty = false;
+    // any-hit "group" mode: a wave owns 64 consecutive rays and writes their bits with one store
+    unsigned group_base = kMiss;
+    bool occ = false;
+    const bool group_mode = ANY && !P.any_atomic;
+
+    auto push = [&](float t_split, unsigned id) {
+        ++sp;
+        const uint2 e = make_uint2(__float_as_uint(t_split), id);
+        if (STACK_N >= 32 || sp < STACK_N) my_stack[sp * BLOCK] = e;
+        else my_spill[(size_t)(sp - STACK_N) * P.spill_stride] = e;
+    };
+    auto peek = [&](int k) -> uint2 {
+        if (STACK_N >= 32 || k < STACK_N) return my_stack[k * BLOCK];
+        return my_spill[(size_t)(k - STACK_N) * P.spill_stride];
+    };
+    auto finish = [&](bool hit) {
+        if (ANY) {
+            if (group_mode) occ = hit;
+            else if (hit) atomicOr(((unsigned*)P.bits) + (ray_idx >> 5), 1u << (ray_idx & 31u));
+        } else {
+            P.hits[ray_idx] = hit ? make_uint4(best_id, __float_as_uint(best_t), __float_as_uint(best_u),
+                                               __float_as_uint(best_v))
+                                  : make_uint4(kMiss, __float_as_uint(FLT_MAX), 0u, 0u);
+        }
+        have_ray = false;
+    };
+
+    for (;;) {
+        const unsigned long long idle = __ballot(!have_ray);
+        const int n_idle = __popcll(idle);
+        if (n_idle >= P.refill_thresh && !pool_empty) {
+            if (group_mode) {
+                const unsigned long long m = __ballot(occ);
+                if (group_base != kMiss && lane == 0) P.bits[group_base >> 6] = m;
+                occ = false;
+            }
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd(P.counter, (unsigned)n_idle);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (base >= P.n || P.n - base <= (unsigned)n_idle) pool_empty = true;
+            if (group_mode) group_base = base < P.n ? base : kMiss;
+            if (!have_ray) {
+                const unsigned rank = __popcll(idle & ((1ull << lane) - 1ull));
+                const unsigned idx = base + rank;
+                if (base < P.n && idx < P.n) {
+                    ray_idx = idx;
+                    best_t = FLT_MAX; best_u = 0.0f; best_v = 0.0f; best_id = kMiss;
+                    bool go = fetch_ray<GEN>(P, idx, r);
+                    if (go) {
+                        // KdTree.hpp:269-274
+                        float entr, exit;
+                        go = box_intersect(P.box, r, entr, exit);
+                        if (go) {
+                            const float nmin = gmax(r.tmin, entr - rescaled_eps(entr));
+                            const float nmax = gmin(r.tmax, exit + rescaled_eps(exit));
+                            r.tmin = nmin; r.tmax = nmax;
+                            root_tmax = nmax;
+                            go = !(best_t < r.tmin);  // KdTree.hpp:280
+                        }
+                    }
+                    if (go) { have_ray = true; node = 0; sp = -1; }
+                    else finish(false);
+                }
+            }
+        }
+        if (__ballot(have_ray) == 0ull) {
+            if (pool_empty) break;
+            continue;
+        }
+        if (have_ray) {
+            // ---- descend to a leaf: KdTree.hpp:284-311 ----
+            uint2 nd = P.nodes[node];
+            while (!(nd.y & 1u)) {
+                const unsigned axis = (nd.y >> 1) & 3u;
+                const unsigned above = nd.y >> 3;
+                const float split = __uint_as_float(nd.x);
+                const float oa = sel3(axis, r.ox, r.oy, r.oz);
+                const float da = sel3(axis, r.dx, r.dy, r.dz);
+                const float ia = sel3(axis, r.ix, r.iy, r.iz);
+                const bool bottom_first = (oa < split) || (oa == split && da <= 0.0f);
+                const unsigned first = bottom_first ? node + 1u : above;
+                const unsigned second = bottom_first ? above : node + 1u;
+                const float t_split = (split - oa) * ia;
+                if (t_split > r.tmax || t_split <= 0.0f) {
+                    node = first;
+                } else if (t_split < r.tmin) {
+                    node = second;
+                } else {
+                    push(t_split, second);
+                    node = first;
+                    r.tmax = t_split + rescaled_eps(t_split);
+                }
+                nd = P.nodes[node];
+            }
+            // ---- leaf: KdTree.hpp:312-333 ----
+            const unsigned n_prims = nd.y >> 1;
+            bool hit = false;
+            for (unsigned i = 0; i < n_prims; ++i) {
+                const unsigned id = (n_prims == 1u) ? nd.x : P.leaf_ids[nd.x + i];
+                if (tri_test(P.tris, id, r, best_t, best_u, best_v, best_id)) {
+                    hit = true;
+                    if (ANY) break;
+                }
+            }
+            if (hit) {
+                finish(true);
+            } else if (sp >= 0) {
+                // ---- pop: KdTree.hpp:334-339.  The reference stores (t_min, t_max, id); t_min is
+                // t_split - eps(t_split) (:305) and the stored t_max is always the t_max set when the
+                // entry below was pushed, t_split' + eps(t_split') (:310), or the root t_max for the
+                // bottom entry, so both are rebuilt from the stored t_split values.
+                const uint2 e = peek(sp);
+                const float ts = __uint_as_float(e.x);
+                node = e.y;
+                r.tmin = ts - rescaled_eps(ts);
+                if (sp > 0) {
+                    const float tb = __uint_as_float(peek(sp - 1).x);
+                    r.tmax = tb + rescaled_eps(tb);
+                } else {
+                    r.tmax = root_tmax;
+                }
+                --sp;
+                if (best_t < r.tmin) finish(false);  // KdTree.hpp:280
+            } else {
+                finish(false);
+            }
+        }
+    }
+    if (group_mode) {
+        const unsigned long long m = __ballot(occ);
+        if (group_base != kMiss && lane == 0) P.bits[group_base >> 6] = m;
+    }
+}
+
+// ---- ray generation as its own pass (for callers that want the rays) ----------------------
+struct Cam12 { float c[12]; };
+__global__ void __launch_bounds__(256) primary_rays_kernel(const Cam12 cam, unsigned res_x, unsigned first,
+                                                           unsigned n, float4* o_tmin, float4* d_tmax) {
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        float dx, dy, dz;
+        primary_ray(cam.c, res_x, first + i, dx, dy, dz);
+        o_tmin[i] = make_float4(cam.c[0], cam.c[1], cam.c[2], 0.0f);
+        d_tmax[i] = make_float4(dx, dy, dz, FLT_MAX);
+    }
+}
+
+// ---- fog: sampleDensity and the GLSL ray march ----------------------------------------------
+struct FogParams {
+    const unsigned char* dens;
+    int rx, ry, rz;
+    float mnx, mny, mnz, mxx, mxy, mxz;
+    float ext_k;
+    int n_intervals;
+};
+
+__device__ __forceinline__ float fog_texel(const FogParams& F, int x, int y, int z) {  // DensityField.cpp:204-211
+    if (x >= 0 && x < F.rx && y >= 0 && y < F.ry && z >= 0 && z < F.rz)
+        return (float)F.dens[x + y * F.rx + z * F.rx * F.ry] / 255.0f;
+    return 0.0f;
+}
+__device__ __forceinline__ float lerp1(float p0, float p1, float t) { return (1.0f - t) * p0 + t * p1; }
+// DensityField.cpp:180-201 from a normalized position; lerp order x, y, z (Interpolation.hpp:8-23)
+__device__ __forceinline__ float fog_filter(const FogParams& F, float nx, float ny, float nz) {
+    const float tcx = nx * (float)F.rx - 0.5f, tcy = ny * (float)F.ry - 0.5f, tcz = nz * (float)F.rz - 0.5f;
+    const float fx = floorf(tcx), fy = floorf(tcy), fz = floorf(tcz);
+    const int x0 = (int)fx, x1 = (int)ceilf(tcx), y0 = (int)fy, y1 = (int)ceilf(tcy), z0 = (int)fz,
+              z1 = (int)ceilf(tcz);
+    const float tx = tcx - (float)x0, ty = tcy - (float)y0, tz = tcz - (float)z0;
+    const float d000 = fog_texel(F, x0, y0, z0), d100 = fog_texel(F, x1, y0, z0);
+    const float d010 = fog_texel(F, x0, y1, z0), d110 = fog_texel(F, x1, y1, z0);
+    const float d001 = fog_texel(F, x0, y0, z1), d101 = fog_texel(F, x1, y0, z1);
+    const float d011 = fog_texel(F, x0, y1, z1), d111 = fog_texel(F, x1, y1, z1);
+    const float i0 = lerp1(lerp1(d000, d100, tx), lerp1(d010, d110, tx), ty);
+    const float i1 = lerp1(lerp1(d001, d101, tx), lerp1(d011, d111, tx), ty);
+    return lerp1(i0, i1, tz);
+}
+// GLSL min/max as selects (Surface.frag:146-153)
+__device__ __forceinline__ float smin(float x, float y) { return y < x ? y : x; }
+__device__ __forceinline__ float smax(float x, float y) { return x < y ? y : x; }
+
+// calcTransm + intersectBBox + rayMarch, Surface.frag:139-203
+__device__ __forceinline__ float calc_transm(const FogParams& F, float px, float py, float pz, float wx, float wy,
+                                             float wz, float dist_sq) {
+    if (!(F.ext_k > 0.0f)) return 1.0f;
+    const float max_dist = sqrtf(dist_sq);
+    const float ivx = 1.0f / wx, ivy = 1.0f / wy, ivz = 1.0f / wz;
+    float t0 = (F.mnx - px) * ivx, t1 = (F.mxx - px) * ivx;
+    float t_min = smin(t0, t1), t_max = smax(t0, t1);
+    t0 = (F.mny - py) * ivy; t1 = (F.mxy - py) * ivy;
+    t_min = smax(t_min, smin(t0, t1)); t_max = smin(t_max, smax(t0, t1));
+    t0 = (F.mnz - pz) * ivz; t1 = (F.mxz - pz) * ivz;
+    t_min = smax(t_min, smin(t0, t1)); t_max = smin(t_max, smax(t0, t1));
+    if (!(t_max > smax(t_min, 0.0f) && t_min < max_dist)) return 1.0f;
+    t_min = smax(t_min, 0.0f);
+    t_max = smin(t_max, max_dist);
+    // inv_fog_dims = 1/(max-min), Source/GIGL.cpp:83
+    const float idx = 1.0f / (F.mxx - F.mnx), idy = 1.0f / (F.mxy - F.mny), idz = 1.0f / (F.mxz - F.mnz);
+    const float dt = (t_max - t_min) / (float)F.n_intervals;
+    auto ext_at = [&](float t) {
+        const float qx = px + t * wx, qy = py + t * wy, qz = pz + t * wz;
+        return F.ext_k * fog_filter(F, (qx - F.mnx) * idx, (qy - F.mny) * idy, (qz - F.mnz) * idz);
+    };
+    float prev = ext_at(t_min), total = 0.0f;
+    for (int i = 1; i <= F.n_intervals; ++i) {
+        const float cur = ext_at(t_min + (float)i * dt);
+        total += 0.5f * (prev + cur);
+        prev = cur;
+    }
+    return expf(-(total * dt));
+}
+
+__global__ void __launch_bounds__(256) transm_segments_kernel(FogParams F, const float4* seg_p,
+                                                              const float4* seg_d, unsigned n, float* out) {
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const float4 p = seg_p[i], d = seg_d[i];
+        out[i] = calc_transm(F, p.x, p.y, p.z, d.x, d.y, d.z, d.w);
+    }
+}
+
+__global__ void __launch_bounds__(256) transm_shadow_kernel(FogParams F, TraceParams P, float* out) {
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < P.n; i += gridDim.x * 256u) {
+        ShadowSeg s;
+        float tr = 1.0f;
+        if (shadow_segment(P, i, s)) tr = calc_transm(F, s.px, s.py, s.pz, s.wx, s.wy, s.wz, s.dist_sq);
+        out[i] = tr;
+    }
+}
+
+__global__ void __launch_bounds__(256) sample_density_kernel(FogParams F, const float* pos, unsigned n, float* out) {
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        // computeNormPos: (pos - min) / dims, BBox.cpp:53-55
+        const float nx = (pos[3 * i] - F.mnx) / (F.mxx - F.mnx);
+        const float ny = (pos[3 * i + 1] - F.mny) / (F.mxy - F.mny);
+        const float nz = (pos[3 * i + 2] - F.mnz) / (F.mxz - F.mnz);
+        out[i] = fog_filter(F, nx, ny, nz);
+    }
+}
+
+__global__ void __launch_bounds__(256) eps_kernel(const float* t, unsigned n, float* out) {
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) out[i] = rescaled_eps(t[i]);
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice ? GIGL_ERR_NO_DEVICE \
+                                                                              : GIGL_ERR_HIP,      \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                        \
+    } while (0)
+
+struct Options {
+    int stack_lds = 12;       // LDS entries per lane: 8, 12, 16 or 32
+    int refill_thresh = 16;   // idle lanes that trigger a refill (closest-hit / atomic any-hit)
+    int any_atomic = 0;       // 0: any-hit waves own 64 consecutive rays; 1: refill + atomicOr
+    int blocks_per_cu = 0;    // 0: occupancy query
+};
+Options g_opt;
+std::mutex g_opt_mu;
+
+constexpr int kBlock = 256;
+constexpr unsigned kMaxRays = 0xF0000000u;
+
+}  // namespace
+
+struct gigl_scene {
+    int device = 0;
+    int n_cus = 0;
+    gigl::KdTreeHost tree;
+    uint32_t n_tris = 0;
+    uint2* d_nodes = nullptr;
+    unsigned* d_leaf_ids = nullptr;
+    float4* d_tris = nullptr;
+    BoxF box;
+    gigl_tree_stats stats;
+    // staging for gigl_trace_one
+    float4* d_one = nullptr;   // 2 float4 in, 1 uint4 out
+    std::mutex one_mu;
+};
+
+struct gigl_fog {
+    int device = 0;
+    unsigned char* d_dens = nullptr;
+    FogParams fp;
+};
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+template <bool ANY, int GEN, int STACK_N>
+int launch_trace_t(const gigl_scene* s, TraceParams& P, const Options& opt, hipStream_t st) {
+    auto kern = trace_kernel<ANY, GEN, STACK_N, kBlock>;
+    int per_cu = opt.blocks_per_cu;
+    if (per_cu <= 0) {
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kBlock, 0));
+        if (per_cu < 1) per_cu = 1;
+    }
+    unsigned grid = (unsigned)(s->n_cus * per_cu);
+    const unsigned need = (P.n + kBlock - 1) / kBlock;
+    if (grid > need) grid = need;
+    if (grid == 0) return GIGL_OK;
+    const bool spill = STACK_N < 32 && s->tree.actual_depth - 1 > STACK_N;
+    const size_t spill_entries = spill ? (size_t)grid * kBlock * (size_t)(32 - STACK_N) : 0;
+    const size_t ws_bytes = 256 + spill_entries * sizeof(uint2);
+    void* ws = nullptr;
+    HIP_TRY(hipMallocAsync(&ws, ws_bytes, st));
+    HIP_TRY(hipMemsetAsync(ws, 0, 256, st));
+    P.counter = (unsigned*)ws;
+    P.spill = (uint2*)((char*)ws + 256);
+    P.spill_stride = grid * kBlock;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, st, P);
+    hipError_t le = hipGetLastError();
+    hipError_t fe = hipFreeAsync(ws, st);
+    if (le != hipSuccess) return fail(GIGL_ERR_HIP, std::string("trace kernel launch: ") + hipGetErrorString(le));
+    if (fe != hipSuccess) return fail(GIGL_ERR_HIP, std::string("hipFreeAsync: ") + hipGetErrorString(fe));
+    return GIGL_OK;
+}
+
+template <bool ANY, int GEN>
+int launch_trace(const gigl_scene* s, TraceParams& P, hipStream_t st) {
+    Options opt;
+    {
+        std::lock_guard<std::mutex> lk(g_opt_mu);
+        opt = g_opt;
+    }
+    P.nodes = s->d_nodes;
+    P.leaf_ids = s->d_leaf_ids;
+    P.tris = s->d_tris;
+    P.box = s->box;
+    P.any_atomic = ANY ? opt.any_atomic : 0;
+    P.refill_thresh = (ANY && !P.any_atomic) ? 64 : opt.refill_thresh;
+    if (P.refill_thresh < 1) P.refill_thresh = 1;
+    if (P.refill_thresh > 64) P.refill_thresh = 64;
+    if (ANY && P.any_atomic)
+        if (hipMemsetAsync(P.bits, 0, ((size_t)P.n + 63) / 64 * 8, st) != hipSuccess)
+            return fail(GIGL_ERR_HIP, "hipMemsetAsync(bits)");
+    // smallest LDS stack that holds the deepest possible stack avoids the spill path entirely
+    int sn = opt.stack_lds;
+    const int deepest = s->tree.actual_depth - 1;
+    if (deepest <= 8) sn = 8;
+    else if (deepest <= 12 && sn >= 12) sn = 12;
+    else if (deepest <= 16 && sn >= 16) sn = 16;
+    switch (sn) {
+        case 8: return launch_trace_t<ANY, GEN, 8>(s, P, opt, st);
+        case 12: return launch_trace_t<ANY, GEN, 12>(s, P, opt, st);
+        case 16: return launch_trace_t<ANY, GEN, 16>(s, P, opt, st);
+        case 32: return launch_trace_t<ANY, GEN, 32>(s, P, opt, st);
+        default: return fail(GIGL_ERR_INVALID, "option stack_lds must be 8, 12, 16 or 32");
+    }
+}
+
+int check_batch(const gigl_scene* s, const void* a, const void* b, uint64_t n, const void* out) {
+    if (!s) return fail(GIGL_ERR_INVALID, "scene is NULL");
+    if (s->device == GIGL_DEVICE_NONE) return fail(GIGL_ERR_NO_DEVICE, "host-only scene: no device to trace on");
+    if (n == 0) return GIGL_OK;
+    if (!a || !b || !out) return fail(GIGL_ERR_INVALID, "NULL ray or output pointer");
+    if (n > kMaxRays) return fail(GIGL_ERR_TOO_LARGE, "at most 0xF0000000 rays per call");
+    return GIGL_OK;
+}
+
+unsigned stream_grid(const gigl_scene* s, uint64_t n) {
+    uint64_t g = (n + 255) / 256;
+    const uint64_t cap = (uint64_t)(s ? s->n_cus : 256) * 8;
+    return (unsigned)(g < cap ? (g ? g : 1) : cap);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* gigl_last_error(void) { return g_err.c_str(); }
+
+int gigl_device_count(int* count) {
+    if (!count) return fail(GIGL_ERR_INVALID, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(GIGL_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    }
+    *count = n;
+    return GIGL_OK;
+}
+
+int gigl_set_option(const char* name, int value) {
+    if (!name) return fail(GIGL_ERR_INVALID, "name is NULL");
+    std::lock_guard<std::mutex> lk(g_opt_mu);
+    const std::string k(name);
+    if (k == "stack_lds") {
+        if (value != 8 && value != 12 && value != 16 && value != 32)
+            return fail(GIGL_ERR_INVALID, "stack_lds must be 8, 12, 16 or 32");
+        g_opt.stack_lds = value;
+    } else if (k == "refill_thresh") {
+        if (value < 1 || value > 64) return fail(GIGL_ERR_INVALID, "refill_thresh must be in 1..64");
+        g_opt.refill_thresh = value;
+    } else if (k == "any_atomic") {
+        g_opt.any_atomic = value ? 1 : 0;
+    } else if (k == "blocks_per_cu") {
+        if (value < 0 || value > 8) return fail(GIGL_ERR_INVALID, "blocks_per_cu must be in 0..8");
+        g_opt.blocks_per_cu = value;
+    } else {
+        return fail(GIGL_ERR_INVALID, "unknown option " + k);
+    }
+    return GIGL_OK;
+}
+
+int gigl_scene_create(const float* verts, uint32_t n_verts, const uint32_t* tris, uint32_t n_tris,
+                      int inters_cost, int trav_cost, int max_depth, uint32_t min_num_prims, float empty_bonus,
+                      int device, gigl_scene** out) {
+    if (!out) return fail(GIGL_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if ((!verts && n_verts) || (!tris && n_tris)) return fail(GIGL_ERR_INVALID, "NULL vertex or triangle array");
+    const bool host_only = device == GIGL_DEVICE_NONE;
+    if (!host_only) {
+        int n_dev = 0;
+        if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+            return fail(GIGL_ERR_NO_DEVICE, "no HIP device: the engine has no CPU fallback");
+        if (device < 0 || device >= n_dev) return fail(GIGL_ERR_INVALID, "device index out of range");
+    }
+
+    gigl_scene* s = new gigl_scene();
+    s->device = device;
+    s->n_tris = n_tris;
+    gigl::KdBuildParams bp;
+    bp.inters_cost = inters_cost; bp.trav_cost = trav_cost; bp.max_depth = max_depth;
+    bp.min_num_prims = min_num_prims; bp.empty_bonus = empty_bonus;
+    const char* err = nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (!gigl::kd_build(verts, n_verts, tris, n_tris, bp, s->tree, &err)) {
+        delete s;
+        return fail(GIGL_ERR_BUILD, err ? err : "k-d tree build failed");
+    }
+    const auto t1 = std::chrono::steady_clock::now();
+    {
+        gigl_tree_stats& S = s->stats;
+        S.n_nodes = (uint32_t)s->tree.nodes.size();
+        S.n_leaf_prim_ids = (uint32_t)s->tree.leaf_prim_ids.size();
+        S.leaf_count = s->tree.leaf_count;
+        S.max_depth = s->tree.max_depth;
+        S.actual_depth = s->tree.actual_depth;
+        S.avg_prims_per_leaf = s->tree.leaf_count ? (float)(s->tree.prims_in_leaves / s->tree.leaf_count) : 0.0f;
+        S.build_ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
+        S.degenerate_split_guard_hit = s->tree.degenerate_split_guard_hit ? 1u : 0u;
+        S.device_bytes = 0;
+    }
+    if (host_only) {  // tree only: bbox/stats/export work, every trace call reports GIGL_ERR_NO_DEVICE
+        *out = s;
+        return GIGL_OK;
+    }
+
+    // flattened triangle records: p0, e0 = p1 - p0, e1 = p2 - p0 (RTBase.cpp:151-155)
+    std::vector<float> rec((size_t)n_tris * 12, 0.0f);
+    for (uint32_t i = 0; i < n_tris; ++i) {
+        const float* p0 = verts + 3 * (size_t)tris[4 * (size_t)i];
+        const float* p1 = verts + 3 * (size_t)tris[4 * (size_t)i + 1];
+        const float* p2 = verts + 3 * (size_t)tris[4 * (size_t)i + 2];
+        float* r = &rec[(size_t)i * 12];
+        r[0] = p0[0]; r[1] = p0[1]; r[2] = p0[2];
+        r[3] = p1[0] - p0[0]; r[4] = p1[1] - p0[1]; r[5] = p1[2] - p0[2];
+        r[6] = p2[0] - p0[0]; r[7] = p2[1] - p0[1]; r[8] = p2[2] - p0[2];
+        uint32_t mat = tris[4 * (size_t)i + 3];
+        memcpy(&r[9], &mat, 4);
+    }
+    DeviceGuard g(device);
+    if (!g.ok) { delete s; return fail(GIGL_ERR_NO_DEVICE, "hipSetDevice failed"); }
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) { delete s; return fail(GIGL_ERR_HIP, "hipGetDeviceProperties failed"); }
+    s->n_cus = prop.multiProcessorCount;
+    // keep the stream-ordered pool's memory between calls
+    hipMemPool_t pool;
+    if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess) {
+        uint64_t thr = UINT64_MAX;
+        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr);
+    }
+    const size_t nb_nodes = std::max<size_t>(s->tree.nodes.size(), 1) * sizeof(uint2);
+    const size_t nb_leaf = std::max<size_t>(s->tree.leaf_prim_ids.size(), 1) * 4;
+    const size_t nb_tris = std::max<size_t>(rec.size(), 12) * 4;
+    auto cleanup = [&]() {
+        if (s->d_nodes) (void)hipFree(s->d_nodes);
+        if (s->d_leaf_ids) (void)hipFree(s->d_leaf_ids);
+        if (s->d_tris) (void)hipFree(s->d_tris);
+        if (s->d_one) (void)hipFree(s->d_one);
+        delete s;
+    };
+#define CREATE_TRY(expr)                                                                      \
+    do {                                                                                      \
+        hipError_t e2_ = (expr);                                                              \
+        if (e2_ != hipSuccess) {                                                              \
+            cleanup();                                                                        \
+            return fail(GIGL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e2_));    \
+        }                                                                                     \
+    } while (0)
+    CREATE_TRY(hipMalloc((void**)&s->d_nodes, nb_nodes));
+    CREATE_TRY(hipMalloc((void**)&s->d_leaf_ids, nb_leaf));
+    CREATE_TRY(hipMalloc((void**)&s->d_tris, nb_tris));
+    CREATE_TRY(hipMalloc((void**)&s->d_one, 64));
+    if (!s->tree.nodes.empty())
+        CREATE_TRY(hipMemcpy(s->d_nodes, s->tree.nodes.data(), s->tree.nodes.size() * 8, hipMemcpyHostToDevice));
+    else {
+        // empty scene: a single empty leaf (KdTree.hpp:9-12)
+        const uint2 leaf = make_uint2(0u, 1u);
+        CREATE_TRY(hipMemcpy(s->d_nodes, &leaf, 8, hipMemcpyHostToDevice));
+    }
+    if (!s->tree.leaf_prim_ids.empty())
+        CREATE_TRY(hipMemcpy(s->d_leaf_ids, s->tree.leaf_prim_ids.data(), s->tree.leaf_prim_ids.size() * 4,
+                             hipMemcpyHostToDevice));
+    if (!rec.empty()) CREATE_TRY(hipMemcpy(s->d_tris, rec.data(), rec.size() * 4, hipMemcpyHostToDevice));
+#undef CREATE_TRY
+    s->box = BoxF{s->tree.box_min[0], s->tree.box_min[1], s->tree.box_min[2],
+                  s->tree.box_max[0], s->tree.box_max[1], s->tree.box_max[2]};
+    s->stats.device_bytes = nb_nodes + nb_leaf + nb_tris;
+    *out = s;
+    return GIGL_OK;
+}
+
+int gigl_scene_destroy(gigl_scene* s) {
+    if (!s) return GIGL_OK;
+    if (s->device == GIGL_DEVICE_NONE) { delete s; return GIGL_OK; }
+    DeviceGuard g(s->device);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(s->d_nodes);
+    (void)hipFree(s->d_leaf_ids);
+    (void)hipFree(s->d_tris);
+    (void)hipFree(s->d_one);
+    delete s;
+    return GIGL_OK;
+}
+
+int gigl_scene_bbox(const gigl_scene* s, float out[6]) {
+    if (!s || !out) return fail(GIGL_ERR_INVALID, "NULL argument");
+    for (int a = 0; a < 3; ++a) { out[a] = s->tree.box_min[a]; out[3 + a] = s->tree.box_max[a]; }
+    return GIGL_OK;
+}
+
+int gigl_scene_stats(const gigl_scene* s, gigl_tree_stats* out) {
+    if (!s || !out) return fail(GIGL_ERR_INVALID, "NULL argument");
+    *out = s->stats;
+    return GIGL_OK;
+}
+
+int gigl_scene_export_tree(const gigl_scene* s, uint32_t* nodes_words, uint32_t* leaf_prim_ids) {
+    if (!s) return fail(GIGL_ERR_INVALID, "scene is NULL");
+    if (nodes_words && !s->tree.nodes.empty()) memcpy(nodes_words, s->tree.nodes.data(), s->tree.nodes.size() * 8);
+    if (leaf_prim_ids && !s->tree.leaf_prim_ids.empty())
+        memcpy(leaf_prim_ids, s->tree.leaf_prim_ids.data(), s->tree.leaf_prim_ids.size() * 4);
+    return GIGL_OK;
+}
+
+int gigl_trace_closest_device(const gigl_scene* s, const void* o_tmin, const void* d_tmax, uint64_t n,
+                              gigl_hit* hits, void* stream) {
+    int rc = check_batch(s, o_tmin, d_tmax, n, hits);
+    if (rc != GIGL_OK || n == 0) return rc;
+    DeviceGuard g(s->device);
+    TraceParams P = {};
+    P.n = (unsigned)n;
+    P.o_tmin = (const float4*)o_tmin;
+    P.d_tmax = (const float4*)d_tmax;
+    P.hits = (uint4*)hits;
+    return launch_trace<false, 0>(s, P, (hipStream_t)stream);
+}
+
+int gigl_trace_any_device(const gigl_scene* s, const void* o_tmin, const void* d_tmax, uint64_t n,
+                          uint64_t* occluded_bits, void* stream) {
+    int rc = check_batch(s, o_tmin, d_tmax, n, occluded_bits);
+    if (rc != GIGL_OK || n == 0) return rc;
+    DeviceGuard g(s->device);
+    TraceParams P = {};
+    P.n = (unsigned)n;
+    P.o_tmin = (const float4*)o_tmin;
+    P.d_tmax = (const float4*)d_tmax;
+    P.bits = (unsigned long long*)occluded_bits;
+    return launch_trace<true, 0>(s, P, (hipStream_t)stream);
+}
+
+static int trace_host(const gigl_scene* s, const float* o_tmin, const float* d_tmax, uint64_t n, void* out,
+                      size_t out_bytes, bool any) {
+    int rc = check_batch(s, o_tmin, d_tmax, n, out);
+    if (rc != GIGL_OK || n == 0) return rc;
+    DeviceGuard g(s->device);
+    void *d_o = nullptr, *d_d = nullptr, *d_out = nullptr;
+    auto release = [&]() {
+        if (d_o) (void)hipFree(d_o);
+        if (d_d) (void)hipFree(d_d);
+        if (d_out) (void)hipFree(d_out);
+    };
+#define HOST_TRY(expr)                                                                    \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            release();                                                                    \
+            return fail(GIGL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+        }                                                                                 \
+    } while (0)
+    HOST_TRY(hipMalloc(&d_o, n * 16));
+    HOST_TRY(hipMalloc(&d_d, n * 16));
+    HOST_TRY(hipMalloc(&d_out, out_bytes));
+    HOST_TRY(hipMemcpy(d_o, o_tmin, n * 16, hipMemcpyHostToDevice));
+    HOST_TRY(hipMemcpy(d_d, d_tmax, n * 16, hipMemcpyHostToDevice));
+    rc = any ? gigl_trace_any_device(s, d_o, d_d, n, (uint64_t*)d_out, nullptr)
+             : gigl_trace_closest_device(s, d_o, d_d, n, (gigl_hit*)d_out, nullptr);
+    if (rc != GIGL_OK) { release(); return rc; }
+    HOST_TRY(hipDeviceSynchronize());
+    HOST_TRY(hipMemcpy(out, d_out, out_bytes, hipMemcpyDeviceToHost));
+#undef HOST_TRY
+    release();
+    return GIGL_OK;
+}
+
+int gigl_trace_closest(const gigl_scene* s, const float* o_tmin, const float* d_tmax, uint64_t n, gigl_hit* hits) {
+    return trace_host(s, o_tmin, d_tmax, n, hits, n * sizeof(gigl_hit), false);
+}
+
+int gigl_trace_any(const gigl_scene* s, const float* o_tmin, const float* d_tmax, uint64_t n,
+                   uint64_t* occluded_bits) {
+    return trace_host(s, o_tmin, d_tmax, n, occluded_bits, (n + 63) / 64 * 8, true);
+}
+
+int gigl_trace_one(const gigl_scene* s, const float o[3], const float d[3], float t_min, float t_max,
+                   int is_vis_ray, int* hit_out, gigl_hit* hit_rec, float normal_out[3]) {
+    if (!s || !o || !d || !hit_out) return fail(GIGL_ERR_INVALID, "NULL argument");
+    if (s->device == GIGL_DEVICE_NONE) return fail(GIGL_ERR_NO_DEVICE, "host-only scene: no device to trace on");
+    // Scene::trace semantics on one ray: a closest-hit launch answers both modes (the bool of a
+    // visibility ray equals the bool of the closest-hit query; only the early-out differs).
+    const float ro[4] = {o[0], o[1], o[2], t_min}, rd[4] = {d[0], d[1], d[2], t_max};
+    gigl_hit h;
+    std::lock_guard<std::mutex> lk(const_cast<gigl_scene*>(s)->one_mu);
+    DeviceGuard g(s->device);
+    HIP_TRY(hipMemcpy(s->d_one, ro, 16, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->d_one + 1, rd, 16, hipMemcpyHostToDevice));
+    int rc = gigl_trace_closest_device(s, s->d_one, s->d_one + 1, 1, (gigl_hit*)(s->d_one + 2), nullptr);
+    if (rc != GIGL_OK) return rc;
+    HIP_TRY(hipMemcpy(&h, s->d_one + 2, 16, hipMemcpyDeviceToHost));
+    *hit_out = h.tri_id != GIGL_MISS;
+    if (hit_rec) *hit_rec = h;
+    if (normal_out) {
+        normal_out[0] = normal_out[1] = normal_out[2] = 0.0f;
+        if (*hit_out) {
+            // cross(edge0, edge1) (RTBase.cpp:170); normalized for non-visibility rays (Scene.cpp:238)
+            const gigl::KdTreeHost& T = s->tree;
+            (void)T;
+            float rec[12];
+            HIP_TRY(hipMemcpy(rec, s->d_tris + 3 * (size_t)h.tri_id, 48, hipMemcpyDeviceToHost));
+            const float e0x = rec[3], e0y = rec[4], e0z = rec[5], e1x = rec[6], e1y = rec[7], e1z = rec[8];
+            float nx = e0y * e1z - e1y * e0z, ny = e0z * e1x - e1z * e0x, nz = e0x * e1y - e1x * e0y;
+            if (!is_vis_ray) {
+                const float sqr = nx * nx + ny * ny + nz * nz;
+                const float inv = 1.0f / sqrtf(sqr);
+                nx = nx * inv; ny = ny * inv; nz = nz * inv;
+            }
+            normal_out[0] = nx; normal_out[1] = ny; normal_out[2] = nz;
+        }
+    }
+    return GIGL_OK;
+}
+
+int gigl_camera_setup(const float pos[3], const float dir[3], const float up[3], float h_fov, int res_x,
+                      int res_y, float cam_out[12]) {
+    if (!pos || !dir || !up || !cam_out || res_x <= 0 || res_y <= 0) return fail(GIGL_ERR_INVALID, "bad camera");
+    // Camera.cpp:15-29, GLM operation order
+    auto norm = [](float v[3]) {
+        const float sqr = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+        const float inv = 1.0f / sqrtf(sqr);
+        v[0] = v[0] * inv; v[1] = v[1] * inv; v[2] = v[2] * inv;
+    };
+    auto cross = [](const float x[3], const float y[3], float o[3]) {
+        o[0] = x[1] * y[2] - y[1] * x[2]; o[1] = x[2] * y[0] - y[2] * x[0]; o[2] = x[0] * y[1] - y[0] * x[1];
+    };
+    const float aspect = (float)res_x / (float)res_y;
+    float fwd[3] = {dir[0], dir[1], dir[2]}, right[3], upa[3];
+    norm(fwd);
+    cross(fwd, up, right); norm(right);
+    cross(right, fwd, upa); norm(upa);
+    const float k = 2.0f * tanf(0.5f * h_fov);
+    for (int a = 0; a < 3; ++a) {
+        const float row = (k * right[a]) * aspect, col = k * upa[a];
+        cam_out[a] = pos[a];
+        cam_out[3 + a] = (fwd[a] - 0.5f * row) - 0.5f * col;
+        cam_out[6 + a] = row / (float)res_x;
+        cam_out[9 + a] = col / (float)res_y;
+    }
+    return GIGL_OK;
+}
+
+int gigl_gen_primary_rays_device(const gigl_scene* s, const float cam[12], int res_x, uint64_t first, uint64_t n,
+                                 void* o_tmin, void* d_tmax, void* stream) {
+    if (!s || !cam || res_x <= 0) return fail(GIGL_ERR_INVALID, "bad argument");
+    if (s->device == GIGL_DEVICE_NONE) return fail(GIGL_ERR_NO_DEVICE, "host-only scene: no device to trace on");
+    if (n == 0) return GIGL_OK;
+    if (!o_tmin || !d_tmax) return fail(GIGL_ERR_INVALID, "NULL output");
+    if (n > kMaxRays || first + n > 0xFFFFFFFFull) return fail(GIGL_ERR_TOO_LARGE, "pixel range too large");
+    DeviceGuard g(s->device);
+    Cam12 c;
+    memcpy(c.c, cam, sizeof(c.c));
+    hipLaunchKernelGGL(primary_rays_kernel, dim3(stream_grid(s, n)), dim3(256), 0, (hipStream_t)stream, c,
+                       (unsigned)res_x, (unsigned)first, (unsigned)n, (float4*)o_tmin, (float4*)d_tmax);
+    HIP_TRY(hipGetLastError());
+    return GIGL_OK;
+}
+
+int gigl_trace_primary_device(const gigl_scene* s, const float cam[12], int res_x, uint64_t first, uint64_t n,
+                              gigl_hit* hits, void* stream) {
+    if (!s || !cam || res_x <= 0) return fail(GIGL_ERR_INVALID, "bad argument");
+    if (s->device == GIGL_DEVICE_NONE) return fail(GIGL_ERR_NO_DEVICE, "host-only scene: no device to trace on");
+    if (n == 0) return GIGL_OK;
+    if (!hits) return fail(GIGL_ERR_INVALID, "NULL output");
+    if (n > kMaxRays || first + n > 0xFFFFFFFFull) return fail(GIGL_ERR_TOO_LARGE, "pixel range too large");
+    DeviceGuard g(s->device);
+    TraceParams P = {};
+    P.n = (unsigned)n;
+    memcpy(P.cam, cam, sizeof(P.cam));
+    P.res_x = (unsigned)res_x;
+    P.first = (unsigned)first;
+    P.hits = (uint4*)hits;
+    return launch_trace<false, 1>(s, P, (hipStream_t)stream);
+}
+
+int gigl_shadow_batch_device(const gigl_scene* s, const void* prim_o_tmin, const void* prim_d_tmax,
+                             const gigl_hit* prim_hits, uint64_t n_pts, const float* lights, uint32_t n_lights,
+                             uint64_t* occluded_bits, const gigl_fog* fog, float* transm, void* stream) {
+    if (!s) return fail(GIGL_ERR_INVALID, "scene is NULL");
+    if (s->device == GIGL_DEVICE_NONE) return fail(GIGL_ERR_NO_DEVICE, "host-only scene: no device to trace on");
+    const uint64_t n = n_pts * (uint64_t)n_lights;
+    if (n == 0) return GIGL_OK;
+    if (!prim_o_tmin || !prim_d_tmax || !prim_hits || !lights) return fail(GIGL_ERR_INVALID, "NULL input");
+    if (!occluded_bits && !transm) return fail(GIGL_ERR_INVALID, "no output requested");
+    if (transm && !fog) return fail(GIGL_ERR_INVALID, "transm requested without fog");
+    if (n > kMaxRays) return fail(GIGL_ERR_TOO_LARGE, "n_pts * n_lights must stay below 0xF0000000");
+    if (fog && fog->device != s->device) return fail(GIGL_ERR_INVALID, "fog and scene live on different devices");
+    DeviceGuard g(s->device);
+    TraceParams P = {};
+    P.n = (unsigned)n;
+    P.prim_o = (const float4*)prim_o_tmin;
+    P.prim_d = (const float4*)prim_d_tmax;
+    P.prim_hits = (const uint4*)prim_hits;
+    P.lights = lights;
+    P.n_lights = n_lights;
+    P.bits = (unsigned long long*)occluded_bits;
+    if (occluded_bits) {
+        int rc = launch_trace<true, 2>(s, P, (hipStream_t)stream);
+        if (rc != GIGL_OK) return rc;
+    }
+    if (transm) {
+        P.tris = s->d_tris;
+        hipLaunchKernelGGL(transm_shadow_kernel, dim3(stream_grid(s, n)), dim3(256), 0, (hipStream_t)stream, fog->fp,
+                           P, transm);
+        HIP_TRY(hipGetLastError());
+    }
+    return GIGL_OK;
+}
+
+int gigl_fog_create(const uint8_t* dens, const int res[3], const float box[6], float ext_k, int n_intervals,
+                    int device, gigl_fog** out) {
+    if (!out) return fail(GIGL_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!dens || !res || !box) return fail(GIGL_ERR_INVALID, "NULL argument");
+    if (res[0] <= 0 || res[1] <= 0 || res[2] <= 0 || (int64_t)res[0] * res[1] * res[2] > (1ll << 30))
+        return fail(GIGL_ERR_INVALID, "bad volume resolution");
+    if (n_intervals < 1 || n_intervals > 4096) return fail(GIGL_ERR_INVALID, "n_intervals must be in 1..4096");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+        return fail(GIGL_ERR_NO_DEVICE, "no HIP device: the engine has no CPU fallback");
+    if (device < 0 || device >= n_dev) return fail(GIGL_ERR_INVALID, "device index out of range");
+    DeviceGuard g(device);
+    gigl_fog* f = new gigl_fog();
+    f->device = device;
+    const size_t nb = (size_t)res[0] * res[1] * res[2];
+    hipError_t e = hipMalloc((void**)&f->d_dens, nb);
+    if (e == hipSuccess) e = hipMemcpy(f->d_dens, dens, nb, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (f->d_dens) (void)hipFree(f->d_dens);
+        delete f;
+        return fail(GIGL_ERR_HIP, std::string("fog upload: ") + hipGetErrorString(e));
+    }
+    f->fp = FogParams{f->d_dens, res[0], res[1], res[2], box[0], box[1], box[2], box[3], box[4], box[5], ext_k,
+                      n_intervals};
+    *out = f;
+    return GIGL_OK;
+}
+
+int gigl_fog_destroy(gigl_fog* f) {
+    if (!f) return GIGL_OK;
+    DeviceGuard g(f->device);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(f->d_dens);
+    delete f;
+    return GIGL_OK;
+}
+
+int gigl_transmittance_device(const gigl_fog* f, const void* seg_p, const void* seg_d_distsq, uint64_t n,
+                              float* transm, void* stream) {
+    if (!f) return fail(GIGL_ERR_INVALID, "fog is NULL");
+    if (n == 0) return GIGL_OK;
+    if (!seg_p || !seg_d_distsq || !transm) return fail(GIGL_ERR_INVALID, "NULL pointer");
+    if (n > kMaxRays) return fail(GIGL_ERR_TOO_LARGE, "at most 0xF0000000 segments per call");
+    DeviceGuard g(f->device);
+    hipLaunchKernelGGL(transm_segments_kernel, dim3(stream_grid(nullptr, n)), dim3(256), 0, (hipStream_t)stream,
+                       f->fp, (const float4*)seg_p, (const float4*)seg_d_distsq, (unsigned)n, transm);
+    HIP_TRY(hipGetLastError());
+    return GIGL_OK;
+}
+
+static int map_host(int device, const float* in, size_t in_floats, uint64_t n, float* out,
+                    void (*launch)(const float*, unsigned, float*, const void*), const void* ctx) {
+    DeviceGuard g(device);
+    float *d_in = nullptr, *d_out = nullptr;
+    hipError_t e = hipMalloc((void**)&d_in, in_floats * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_out, n * 4);
+    if (e == hipSuccess) e = hipMemcpy(d_in, in, in_floats * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        launch(d_in, (unsigned)n, d_out, ctx);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(out, d_out, n * 4, hipMemcpyDeviceToHost);
+    if (d_in) (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(GIGL_ERR_HIP, std::string("device map: ") + hipGetErrorString(e));
+    return GIGL_OK;
+}
+
+int gigl_sample_density(const gigl_fog* f, const float* pos, uint64_t n, float* dens_out) {
+    if (!f) return fail(GIGL_ERR_INVALID, "fog is NULL");
+    if (n == 0) return GIGL_OK;
+    if (!pos || !dens_out) return fail(GIGL_ERR_INVALID, "NULL pointer");
+    if (n > (1u << 28)) return fail(GIGL_ERR_TOO_LARGE, "at most 2^28 positions per call");
+    return map_host(f->device, pos, 3 * n, n, dens_out,
+                    [](const float* in, unsigned m, float* o, const void* ctx) {
+                        hipLaunchKernelGGL(sample_density_kernel, dim3((m + 255) / 256), dim3(256), 0, nullptr,
+                                           *(const FogParams*)ctx, in, m, o);
+                    },
+                    &f->fp);
+}
+
+int gigl_debug_rescaled_eps(int device, const float* t, uint64_t n, float* out) {
+    if (n == 0) return GIGL_OK;
+    if (!t || !out) return fail(GIGL_ERR_INVALID, "NULL pointer");
+    if (n > (1u << 28)) return fail(GIGL_ERR_TOO_LARGE, "at most 2^28 values per call");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+        return fail(GIGL_ERR_NO_DEVICE, "no HIP device: the engine has no CPU fallback");
+    if (device < 0 || device >= n_dev) return fail(GIGL_ERR_INVALID, "device index out of range");
+    return map_host(device, t, n, n, out,
+                    [](const float* in, unsigned m, float* o, const void*) {
+                        hipLaunchKernelGGL(eps_kernel, dim3((m + 255) / 256), dim3(256), 0, nullptr, in, m, o);
+                    },
+                    nullptr);
+}
+
+}  // extern "C"

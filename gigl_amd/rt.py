@@ -1,0 +1,250 @@
+"""Host-side Python mirror of the reference's RT interface over the C ABI (include/gigl_rt.h).
+
+Names follow the reference (/root/reference/Source/Common/Scene.h:17-49,
+Source/RT/KdTree.h:14-20): Scene.trace, Scene.bbox, FogVolume ...  Everything here calls
+gigl_amd/lib/libgigl_rt.so through ctypes; there is no CPU path, and a missing library or GPU
+raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgigl_rt.so")
+_LIB = None
+
+GIGL_MISS = 0xFFFFFFFF
+HIT_DTYPE = np.dtype([("tri_id", "<u4"), ("t", "<f4"), ("u", "<f4"), ("v", "<f4")])
+
+# every symbol include/gigl_rt.h declares
+SYMBOLS = [
+    "gigl_last_error", "gigl_device_count", "gigl_scene_create", "gigl_scene_destroy", "gigl_scene_bbox",
+    "gigl_scene_stats", "gigl_scene_export_tree", "gigl_trace_closest_device", "gigl_trace_closest",
+    "gigl_trace_any_device", "gigl_trace_any", "gigl_trace_one", "gigl_camera_setup",
+    "gigl_gen_primary_rays_device", "gigl_trace_primary_device", "gigl_shadow_batch_device", "gigl_fog_create",
+    "gigl_fog_destroy", "gigl_transmittance_device", "gigl_sample_density", "gigl_debug_rescaled_eps",
+    "gigl_set_option",
+]
+
+
+class GiglError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("gigl_rt error %d: %s" % (code, msg))
+        self.code = code
+
+
+class TreeStats(C.Structure):
+    _fields_ = [("n_nodes", C.c_uint32), ("n_leaf_prim_ids", C.c_uint32), ("leaf_count", C.c_uint32),
+                ("max_depth", C.c_int32), ("actual_depth", C.c_int32), ("avg_prims_per_leaf", C.c_float),
+                ("build_ms", C.c_float), ("degenerate_split_guard_hit", C.c_uint32),
+                ("device_bytes", C.c_uint64)]
+
+
+def lib():
+    """Loads the HIP engine; raises if it was not built (no fallback)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("HIP engine missing: %s (build with __graft_entry__.build() or "
+                               "`make -C gigl_amd/csrc`)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        vp, u32, u64, i, f = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_float
+        L.gigl_last_error.restype = C.c_char_p
+        L.gigl_device_count.argtypes = [vp]
+        L.gigl_scene_create.argtypes = [vp, u32, vp, u32, i, i, i, u32, f, i, vp]
+        L.gigl_scene_destroy.argtypes = [vp]
+        L.gigl_scene_bbox.argtypes = [vp, vp]
+        L.gigl_scene_stats.argtypes = [vp, vp]
+        L.gigl_scene_export_tree.argtypes = [vp, vp, vp]
+        L.gigl_trace_closest_device.argtypes = [vp, vp, vp, u64, vp, vp]
+        L.gigl_trace_closest.argtypes = [vp, vp, vp, u64, vp]
+        L.gigl_trace_any_device.argtypes = [vp, vp, vp, u64, vp, vp]
+        L.gigl_trace_any.argtypes = [vp, vp, vp, u64, vp]
+        L.gigl_trace_one.argtypes = [vp, vp, vp, f, f, i, vp, vp, vp]
+        L.gigl_camera_setup.argtypes = [vp, vp, vp, f, i, i, vp]
+        L.gigl_gen_primary_rays_device.argtypes = [vp, vp, i, u64, u64, vp, vp, vp]
+        L.gigl_trace_primary_device.argtypes = [vp, vp, i, u64, u64, vp, vp]
+        L.gigl_shadow_batch_device.argtypes = [vp, vp, vp, vp, u64, vp, u32, vp, vp, vp, vp]
+        L.gigl_fog_create.argtypes = [vp, vp, vp, f, i, i, vp]
+        L.gigl_fog_destroy.argtypes = [vp]
+        L.gigl_transmittance_device.argtypes = [vp, vp, vp, u64, vp, vp]
+        L.gigl_sample_density.argtypes = [vp, vp, u64, vp]
+        L.gigl_debug_rescaled_eps.argtypes = [i, vp, u64, vp]
+        L.gigl_set_option.argtypes = [C.c_char_p, i]
+        for s in SYMBOLS:
+            if s != "gigl_last_error":
+                getattr(L, s).restype = C.c_int
+        _LIB = L
+    return _LIB
+
+
+def _check(rc):
+    if rc != 0:
+        raise GiglError(rc, lib().gigl_last_error().decode("utf-8", "replace"))
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def device_count():
+    n = C.c_int(0)
+    _check(lib().gigl_device_count(C.byref(n)))
+    return n.value
+
+
+def set_option(name, value):
+    _check(lib().gigl_set_option(name.encode(), int(value)))
+
+
+def camera_setup(pos, direction, up, h_fov, res_x, res_y):
+    out = np.zeros(12, np.float32)
+    _check(lib().gigl_camera_setup(_p(_f32(pos)), _p(_f32(direction)), _p(_f32(up)),
+                                   float(np.float32(h_fov)), res_x, res_y, _p(out)))
+    return out
+
+
+def debug_rescaled_eps(t, device=0):
+    t = _f32(t).ravel()
+    out = np.zeros_like(t)
+    _check(lib().gigl_debug_rescaled_eps(device, _p(t), t.size, _p(out)))
+    return out
+
+
+def unpack_bits(words, n):
+    """uint64 words -> uint8[n] of 0/1 in ray order (bit i%64 of word i/64)."""
+    b = np.unpackbits(np.ascontiguousarray(words, dtype="<u8").view(np.uint8), bitorder="little")
+    return b[:n]
+
+
+class Scene:
+    """Scene's RT half: owns the k-d tree and the triangles on one GPU.
+
+    Scene::loadObjects (RT arrays) + rt::KdTri(m_triangles, 10, 1, 30, 2):
+    /root/reference/Source/Common/Scene.cpp:136-158.
+    """
+
+    def __init__(self, verts, tris, inters_cost=10, trav_cost=1, max_depth=30, min_num_prims=2,
+                 empty_bonus=0.25, device=0):
+        verts = _f32(verts).reshape(-1, 3)
+        tris = np.ascontiguousarray(tris, dtype=np.uint32).reshape(-1, 4)
+        h = C.c_void_p()
+        _check(lib().gigl_scene_create(_p(verts), len(verts), _p(tris), len(tris), inters_cost, trav_cost,
+                                       max_depth, min_num_prims, empty_bonus, device, C.byref(h)))
+        self.h = h
+        self.device = device
+        self.n_tris = len(tris)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().gigl_scene_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def bbox(self):
+        out = np.zeros(6, np.float32)
+        _check(lib().gigl_scene_bbox(self.h, _p(out)))
+        return out
+
+    def stats(self):
+        st = TreeStats()
+        _check(lib().gigl_scene_stats(self.h, C.byref(st)))
+        return st
+
+    def export_tree(self):
+        st = self.stats()
+        nodes = np.zeros((st.n_nodes, 2), np.uint32)
+        leaf = np.zeros(st.n_leaf_prim_ids, np.uint32)
+        _check(lib().gigl_scene_export_tree(self.h, _p(nodes), _p(leaf)))
+        return nodes, leaf
+
+    # ---- host-buffer calls (numpy) ----
+    def trace(self, o_tmin, d_tmax, is_vis_ray=False):
+        """Scene::trace over a batch of fresh rays; returns hit records or 0/1 occlusion bytes."""
+        ro, rd = _f32(o_tmin).reshape(-1, 4), _f32(d_tmax).reshape(-1, 4)
+        n = len(ro)
+        if is_vis_ray:
+            words = np.zeros((n + 63) // 64, np.uint64)
+            _check(lib().gigl_trace_any(self.h, _p(ro), _p(rd), n, _p(words)))
+            return unpack_bits(words, n)
+        hits = np.zeros(n, HIT_DTYPE)
+        _check(lib().gigl_trace_closest(self.h, _p(ro), _p(rd), n, _p(hits)))
+        return hits
+
+    def trace_one(self, o, d, t_min=0.0, t_max=float(np.finfo(np.float32).max), is_vis_ray=False):
+        hit = C.c_int(0)
+        rec = np.zeros(1, HIT_DTYPE)
+        nrm = np.zeros(3, np.float32)
+        _check(lib().gigl_trace_one(self.h, _p(_f32(o)), _p(_f32(d)), t_min, t_max, int(is_vis_ray),
+                                    C.byref(hit), _p(rec), _p(nrm)))
+        return bool(hit.value), rec[0], nrm
+
+    # ---- device-pointer calls (ints from torch.Tensor.data_ptr()) ----
+    def trace_closest_device(self, o_ptr, d_ptr, n, hits_ptr, stream=0):
+        _check(lib().gigl_trace_closest_device(self.h, o_ptr, d_ptr, n, hits_ptr, stream))
+
+    def trace_any_device(self, o_ptr, d_ptr, n, bits_ptr, stream=0):
+        _check(lib().gigl_trace_any_device(self.h, o_ptr, d_ptr, n, bits_ptr, stream))
+
+    def gen_primary_rays_device(self, cam, res_x, first, n, o_ptr, d_ptr, stream=0):
+        _check(lib().gigl_gen_primary_rays_device(self.h, _p(_f32(cam)), res_x, first, n, o_ptr, d_ptr, stream))
+
+    def trace_primary_device(self, cam, res_x, first, n, hits_ptr, stream=0):
+        _check(lib().gigl_trace_primary_device(self.h, _p(_f32(cam)), res_x, first, n, hits_ptr, stream))
+
+    def shadow_batch_device(self, o_ptr, d_ptr, hits_ptr, n_pts, lights_ptr, n_lights, bits_ptr, fog=None,
+                            transm_ptr=None, stream=0):
+        _check(lib().gigl_shadow_batch_device(self.h, o_ptr, d_ptr, hits_ptr, n_pts, lights_ptr, n_lights,
+                                              bits_ptr, fog.h if fog is not None else None, transm_ptr, stream))
+
+
+class FogVolume:
+    """FogVolume/DensityField data on the GPU (/root/reference/Source/Fog/FogVolume.cpp:32-46)."""
+
+    def __init__(self, dens, box, abs_k=1e-5, sca_k=1e-2, n_intervals=8, device=0):
+        dens = np.ascontiguousarray(dens, dtype=np.uint8)
+        assert dens.ndim == 3  # [z][y][x]
+        res = (C.c_int * 3)(dens.shape[2], dens.shape[1], dens.shape[0])
+        box = _f32(box).reshape(6)
+        self.abs_k, self.sca_k = np.float32(abs_k), np.float32(sca_k)
+        self.ext_k = float(self.abs_k + self.sca_k)             # FogVolume.cpp:34
+        h = C.c_void_p()
+        _check(lib().gigl_fog_create(_p(dens), res, _p(box), self.ext_k, n_intervals, device, C.byref(h)))
+        self.h = h
+        self.box = box
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().gigl_fog_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sample_density(self, pos):
+        pos = _f32(pos).reshape(-1, 3)
+        out = np.zeros(len(pos), np.float32)
+        _check(lib().gigl_sample_density(self.h, _p(pos), len(pos), _p(out)))
+        return out
+
+    def sample_ext_k(self, pos):
+        return np.float32(self.ext_k) * self.sample_density(pos)
+
+    def sca_albedo(self):
+        return self.sca_k / (self.abs_k + self.sca_k)           # FogVolume.cpp:43-46
+
+    def transmittance_device(self, seg_p_ptr, seg_d_ptr, n, out_ptr, stream=0):
+        _check(lib().gigl_transmittance_device(self.h, seg_p_ptr, seg_d_ptr, n, out_ptr, stream))

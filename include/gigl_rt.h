@@ -1,0 +1,160 @@
+/*
+ * gigl_rt.h — C ABI of the MI355X ray-query engine (libgigl_rt.so).
+ *
+ * Drop-in boundary for the ray-query hot path of zero-radiance/GIGL.  The reference has no FFI
+ * layer: its RT module is a set of C++ member functions (Scene::trace, KdTree::intersect, ...).
+ * Each entry point below names the reference interface it replaces (path:line under
+ * /root/reference); INTEGRATION.md shows the few lines a maintainer of the reference would
+ * change to call them.
+ *
+ * Conventions
+ *  - Every function returns an int status (GIGL_OK = 0) and never aborts or throws across the
+ *    ABI.  gigl_last_error() returns a thread-local message for the last failure.
+ *    (The reference reports a miss through a bool and fatal errors through TERMINATE(),
+ *    Source/Common/Utility.hpp:52-58.)
+ *  - The library copies what it is given at create time; callers may free their buffers.
+ *  - "_device" pointers are HIP device pointers on the scene's device; `stream` is a
+ *    hipStream_t passed as void* (NULL = the default stream).  Batch calls are asynchronous
+ *    on that stream.  Plain entry points take host pointers and are synchronous.
+ *  - Trace calls may be issued concurrently on one handle (as KdTree::intersect is const and
+ *    re-entrant, Source/Fog/DensityField.cpp:280-293); create/destroy may not.
+ *  - There is no CPU fallback: without a usable HIP device every call fails with
+ *    GIGL_ERR_NO_DEVICE.
+ *
+ * Ray layout (device friendly form of rt::Ray, Source/RT/RTBase.h:81-105): two float4 arrays,
+ *   o_tmin[i] = (o.x, o.y, o.z, t_min)     d_tmax[i] = (d.x, d.y, d.z, t_max)
+ * inv_d is derived as 1.0f/d per component as the Ray constructor does (RTBase.cpp:111-115).
+ * Rays are FRESH: the hit slot starts at distance FLT_MAX (RTBase.cpp:133).
+ */
+#ifndef GIGL_RT_H
+#define GIGL_RT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GIGL_OK             0
+#define GIGL_ERR_INVALID    1   /* bad argument */
+#define GIGL_ERR_NO_DEVICE  2   /* no HIP device / HIP runtime unusable */
+#define GIGL_ERR_HIP        3   /* a HIP call failed */
+#define GIGL_ERR_BUILD      4   /* tree build rejected the input */
+#define GIGL_ERR_TOO_LARGE  5   /* size beyond a documented limit */
+
+#define GIGL_MISS 0xFFFFFFFFu
+/* device index for gigl_scene_create that builds the host tree only (bbox/stats/export work,
+ * every trace call fails with GIGL_ERR_NO_DEVICE); used to check the builder without a GPU */
+#define GIGL_DEVICE_NONE (-1)
+
+typedef struct gigl_scene gigl_scene;   /* replaces Scene's RT half + rt::KdTri */
+typedef struct gigl_fog   gigl_fog;     /* replaces FogVolume/DensityField's sampled data */
+
+/* Closest-hit record.  The reference's Ray::Intersection (Source/RT/RTBase.h:95-100) holds a
+ * material pointer, distance and unnormalized normal; id/u/v identify the same hit without
+ * pointers (u, v are the locals of Triangle::intersect, Source/RT/RTBase.cpp:163-164). */
+typedef struct gigl_hit {
+    uint32_t tri_id;   /* index into the triangle array given at create; GIGL_MISS on a miss */
+    float    t;        /* inters.distance; FLT_MAX on a miss */
+    float    u, v;
+} gigl_hit;
+
+/* Statistics the reference prints after a build (Source/RT/KdTree.hpp:126-131). */
+typedef struct gigl_tree_stats {
+    uint32_t n_nodes;
+    uint32_t n_leaf_prim_ids;
+    uint32_t leaf_count;
+    int32_t  max_depth;
+    int32_t  actual_depth;
+    float    avg_prims_per_leaf;
+    float    build_ms;
+    uint32_t degenerate_split_guard_hit;  /* 1 if a node had no valid split where the reference
+                                             would index out of range (KdTree.hpp:221-232) */
+    uint64_t device_bytes;
+} gigl_tree_stats;
+
+const char* gigl_last_error(void);
+
+/* Device selection ("device-count selector"). */
+int gigl_device_count(int* count);
+
+/* Scene::loadObjects' RT half + rt::KdTree<Triangle>::KdTree
+ * (Source/Common/Scene.cpp:136-158, Source/RT/KdTree.h:14-16, KdTree.hpp:87-264).
+ * verts: float[3*n_verts]; tris: uint32[4*n_tris] = (i0,i1,i2,mat_id); both host pointers.
+ * The tree is built on the host, flattened and uploaded once to `device`. */
+int gigl_scene_create(const float* verts, uint32_t n_verts, const uint32_t* tris, uint32_t n_tris,
+                      int inters_cost, int trav_cost, int max_depth, uint32_t min_num_prims,
+                      float empty_bonus, int device, gigl_scene** out);
+int gigl_scene_destroy(gigl_scene* s);
+/* KdTree::bbox (Source/RT/KdTree.h:18): out = min xyz, max xyz. */
+int gigl_scene_bbox(const gigl_scene* s, float out[6]);
+int gigl_scene_stats(const gigl_scene* s, gigl_tree_stats* out);
+/* The host tree in the reference's 8-byte node encoding (Source/RT/KdTree.h:22-65), for tree
+ * digests: nodes_words uint32[2*n_nodes], leaf_prim_ids uint32[n_leaf_prim_ids]. */
+int gigl_scene_export_tree(const gigl_scene* s, uint32_t* nodes_words, uint32_t* leaf_prim_ids);
+
+/* Scene::trace(ray, false) over a batch (Source/Common/Scene.cpp:234-243 ->
+ * KdTree::intersect, Source/RT/KdTree.hpp:266-347).  n < 2^32. */
+int gigl_trace_closest_device(const gigl_scene* s, const void* o_tmin, const void* d_tmax, uint64_t n,
+                              gigl_hit* hits, void* stream);
+int gigl_trace_closest(const gigl_scene* s, const float* o_tmin, const float* d_tmax, uint64_t n,
+                       gigl_hit* hits);
+/* Scene::trace(ray, true): any-hit.  Bit i of occluded_bits (word i/64, bit i%64) is the bool
+ * the reference returns; ceil(n/64) words are written. */
+int gigl_trace_any_device(const gigl_scene* s, const void* o_tmin, const void* d_tmax, uint64_t n,
+                          uint64_t* occluded_bits, void* stream);
+int gigl_trace_any(const gigl_scene* s, const float* o_tmin, const float* d_tmax, uint64_t n,
+                   uint64_t* occluded_bits);
+/* Single-ray convenience call with Scene::trace semantics (one launch; host pointers).
+ * normal_out (optional) receives the normal as Scene::trace leaves it: normalized for
+ * closest-hit rays, unnormalized cross(e0,e1) for visibility rays. */
+int gigl_trace_one(const gigl_scene* s, const float o[3], const float d[3], float t_min, float t_max,
+                   int is_vis_ray, int* hit_out, gigl_hit* hit_rec, float normal_out[3]);
+
+/* PerspectiveCamera (Source/Common/Camera.cpp:15-33): cam = pos, bottom_left, step_x, step_y. */
+int gigl_camera_setup(const float pos[3], const float dir[3], const float up[3], float h_fov,
+                      int res_x, int res_y, float cam_out[12]);
+/* getPrimaryRay(x+0.5, y+0.5) for pixels [first, first+n) in row-major order
+ * (Source/Common/Camera.cpp:65-68, Source/Fog/DensityField.cpp:288), generated on the device. */
+int gigl_gen_primary_rays_device(const gigl_scene* s, const float cam[12], int res_x, uint64_t first,
+                                 uint64_t n, void* o_tmin, void* d_tmax, void* stream);
+/* Primary closest-hit with the ray generator fused into the traversal kernel. */
+int gigl_trace_primary_device(const gigl_scene* s, const float cam[12], int res_x, uint64_t first,
+                              uint64_t n, gigl_hit* hits, void* stream);
+
+/* Shadow/occlusion batch: for each primary hit point x each light, one visibility ray
+ * (the occlusion test Source/Shaders/Surface.frag:270-276 does with shadow maps, re-expressed
+ * as Scene::trace(ray, true); ray construction in DESIGN.md "Shadow batch").
+ * Pair index = point * n_lights + light; bit layout as gigl_trace_any; points whose primary
+ * ray missed produce 0 bits.  lights: float[3*n_lights] device.  If fog and transm are given,
+ * transm[pair] receives calcTransm (Source/Shaders/Surface.frag:190-203) of the same segment
+ * (1.0 for missed points).  n_pts * n_lights < 2^32. */
+int gigl_shadow_batch_device(const gigl_scene* s, const void* prim_o_tmin, const void* prim_d_tmax,
+                             const gigl_hit* prim_hits, uint64_t n_pts, const float* lights,
+                             uint32_t n_lights, uint64_t* occluded_bits, const gigl_fog* fog,
+                             float* transm, void* stream);
+
+/* DensityField data + FogVolume coefficients (Source/Fog/DensityField.cpp:177-211,
+ * Source/Fog/FogVolume.cpp:32-36).  dens: res[0]*res[1]*res[2] bytes, x fastest; box = min, max. */
+int gigl_fog_create(const uint8_t* dens, const int res[3], const float box[6], float ext_k,
+                    int n_intervals, int device, gigl_fog** out);
+int gigl_fog_destroy(gigl_fog* f);
+/* calcTransm/rayMarch (Source/Shaders/Surface.frag:172-203) over explicit segments:
+ * seg_p[i] = (p.x,p.y,p.z,unused), seg_d_distsq[i] = (dir.x,dir.y,dir.z,dist_sq). */
+int gigl_transmittance_device(const gigl_fog* f, const void* seg_p, const void* seg_d_distsq, uint64_t n,
+                              float* transm, void* stream);
+/* DensityField::sampleDensity (Source/Fog/DensityField.cpp:177-202) at n host positions
+ * float[3*n] -> float[n]; evaluated on the device. */
+int gigl_sample_density(const gigl_fog* f, const float* pos, uint64_t n, float* dens_out);
+
+/* rt::getRescaledEPS (Source/RT/RTBase.h:18-29) evaluated on the device for n host floats;
+ * exists so the parity tests can pin the device arithmetic of the traversal epsilon. */
+int gigl_debug_rescaled_eps(int device, const float* t, uint64_t n, float* out);
+
+/* Tuning knobs (process-wide; read at each launch).  Names and meaning in DESIGN.md. */
+int gigl_set_option(const char* name, int value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,265 @@
+"""GPU parity: the HIP engine (through the C ABI) against the CPU oracle on the same inputs.
+
+Bars (BASELINE.json north_star): triangle ids and occlusion bits bit-exact; distance,
+barycentrics and transmittance within 1e-5 relative (in practice the float results are
+bit-identical too, and the tests say so where that holds).
+"""
+import numpy as np
+import pytest
+
+from conftest import fnv1a64_hits
+from gigl_amd import rt, scene_io as S, synth
+from oracle import oracle_py as O
+
+pytestmark = pytest.mark.gpu
+
+FLT_MAX = np.finfo(np.float32).max
+REL_TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def gpu_cornell(cornell):
+    sc = rt.Scene(cornell["verts"], cornell["tris"], device=0, **S.KD_PARAMS)
+    yield sc
+    sc.close()
+
+
+@pytest.fixture(scope="module")
+def s16(cornell):
+    V, T = synth.tessellate(cornell["verts"], cornell["tris"], 16)
+    g = rt.Scene(V, T, device=0, **S.KD_PARAMS)
+    o = O.OracleScene(V, T, **S.KD_PARAMS)
+    yield {"V": V, "T": T, "gpu": g, "ora": o}
+    g.close()
+
+
+def assert_hits_equal(got, want):
+    assert np.array_equal(got["tri_id"], want["tri_id"]), \
+        "id mismatches: %d" % int((got["tri_id"] != want["tri_id"]).sum())
+    for k in ("t", "u", "v"):
+        a, b = got[k].astype(np.float64), want[k].astype(np.float64)
+        rel = np.abs(a - b) / np.maximum(np.abs(b), 1e-30)
+        assert float(rel.max(initial=0.0)) <= REL_TOL, k
+        # stronger than the bar: same bits
+        assert np.array_equal(got[k].view(np.uint32), want[k].view(np.uint32)), k + " bits differ"
+
+
+def test_rescaled_eps_device():
+    t = np.concatenate([
+        np.array([0.0, -0.0, 1.0, -3.0, 0.1, 1092.0847, 1e-38, 1e-40, 1e-45, 3e38, np.inf, -np.inf, np.nan,
+                  2.0 ** 29, 2.0 ** 30, 2.0 ** 31, 2.0 ** 60, 2.0 ** -30, 2.0 ** -32, 2.0 ** -33, 2.0 ** -126],
+                 np.float32),
+        np.random.default_rng(1).standard_normal(4096).astype(np.float32) * np.float32(1e3),
+        np.exp(np.random.default_rng(2).uniform(-80, 80, 4096)).astype(np.float32)])
+    got = rt.debug_rescaled_eps(t)
+    want = np.array([O.rescaled_eps(x) for x in t], np.float32)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_tree_matches_oracle(gpu_cornell, oracle_cornell, facts):
+    nodes, leaf = gpu_cornell.export_tree()
+    assert np.array_equal(nodes, oracle_cornell.nodes())
+    assert np.array_equal(leaf, oracle_cornell.leaf_prim_ids())
+    st = gpu_cornell.stats()
+    assert st.n_nodes == facts["cornell"]["n_nodes"] and st.actual_depth == facts["cornell"]["depth"]
+    assert np.array_equal(gpu_cornell.bbox(), oracle_cornell.bbox())
+
+
+def test_cornell_primary_closest_digest(gpu_cornell, oracle_cornell, cornell_cam, facts):
+    """Config 2, first half: 1024^2 primary rays; pinned by the reference's own digest."""
+    ro, rd = O.primary_rays(cornell_cam, 1024, 0, 1024 * 1024)
+    got = gpu_cornell.trace(ro, rd)
+    assert int((got["tri_id"] != rt.GIGL_MISS).sum()) == facts["primary_1024"]["n_hits"]
+    assert fnv1a64_hits(got) == facts["primary_1024"]["fnv1a64"]["digest"]
+    want = oracle_cornell.trace_closest(ro, rd, n_threads=4)
+    assert_hits_equal(got, want)
+
+
+def test_cornell_primary_any(gpu_cornell, oracle_cornell, cornell_cam):
+    ro, rd = O.primary_rays(cornell_cam, 1024, 0, 1024 * 1024)
+    n = 300_001   # ragged: not a multiple of 64
+    got = gpu_cornell.trace(ro[:n], rd[:n], is_vis_ray=True)
+    want = oracle_cornell.trace_any(ro[:n], rd[:n], n_threads=4)
+    assert np.array_equal(got, want)
+
+
+def test_fused_primary_generator(gpu_cornell, oracle_cornell, cornell_cam):
+    torch = pytest.importorskip("torch")
+    n, first = 200_000, 333_333
+    hits = torch.zeros((n, 4), dtype=torch.int32, device="cuda:0")
+    o = torch.zeros((n, 4), dtype=torch.float32, device="cuda:0")
+    d = torch.zeros((n, 4), dtype=torch.float32, device="cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    gpu_cornell.trace_primary_device(cornell_cam, 1024, first, n, hits.data_ptr(), st)
+    gpu_cornell.gen_primary_rays_device(cornell_cam, 1024, first, n, o.data_ptr(), d.data_ptr(), st)
+    torch.cuda.synchronize()
+    ro, rd = O.primary_rays(cornell_cam, 1024, first, n)
+    assert np.array_equal(o.cpu().numpy().view(np.uint32), ro.view(np.uint32))
+    assert np.array_equal(d.cpu().numpy().view(np.uint32), rd.view(np.uint32))
+    got = hits.cpu().numpy().view(rt.HIT_DTYPE).reshape(-1)
+    assert_hits_equal(got, oracle_cornell.trace_closest(ro, rd, n_threads=4))
+
+
+def test_incoherent_bounce_rays_s16(s16):
+    """Config 3 at reduced tessellation: incoherent cosine-weighted bounce rays."""
+    ro, rd = synth.bounce_rays(s16["V"], s16["T"], 1 << 17, synth.RAY_SEED_16M)
+    got = s16["gpu"].trace(ro, rd)
+    want = s16["ora"].trace_closest(ro, rd, n_threads=4)
+    assert_hits_equal(got, want)
+    occ = s16["gpu"].trace(ro, rd, is_vis_ray=True)
+    assert np.array_equal(occ, s16["ora"].trace_any(ro, rd, n_threads=4))
+    assert np.array_equal(occ.astype(bool), want["tri_id"] != rt.GIGL_MISS)
+
+
+@pytest.mark.parametrize("stack_lds,refill,any_atomic", [(8, 1, 1), (8, 64, 0), (12, 16, 1), (16, 32, 0), (32, 8, 1)])
+def test_launch_options_do_not_change_results(s16, stack_lds, refill, any_atomic):
+    """LDS stack depth (8 forces the global spill path: tree depth 31), refill threshold and the
+    any-hit output mode are scheduling choices only."""
+    ro, rd = synth.bounce_rays(s16["V"], s16["T"], 50_001, 0xABCD01)
+    want = s16["ora"].trace_closest(ro, rd, n_threads=4)
+    try:
+        rt.set_option("stack_lds", stack_lds)
+        rt.set_option("refill_thresh", refill)
+        rt.set_option("any_atomic", any_atomic)
+        assert_hits_equal(s16["gpu"].trace(ro, rd), want)
+        occ = s16["gpu"].trace(ro, rd, is_vis_ray=True)
+        assert np.array_equal(occ.astype(bool), want["tri_id"] != rt.GIGL_MISS)
+    finally:
+        rt.set_option("stack_lds", 12)
+        rt.set_option("refill_thresh", 16)
+        rt.set_option("any_atomic", 0)
+
+
+def test_edge_cases(gpu_cornell, oracle_cornell):
+    # empty batch
+    assert len(gpu_cornell.trace(np.zeros((0, 4), np.float32), np.zeros((0, 4), np.float32))) == 0
+    inf = np.float32(np.inf)
+    rays = [
+        # o, tmin, d, tmax
+        ([278, 273, -800], 0, [0, 0, 1], FLT_MAX),          # plain hit
+        ([278, 273, -800], 0, [0, 0, -1], FLT_MAX),         # misses the tree box
+        ([278, 273, -800], 0, [0, 0, 1], 100.0),            # range ends before the box
+        ([278, 273, -800], 2000.0, [0, 0, 1], FLT_MAX),     # range starts behind everything
+        ([278, 273, 100], 0, [0, 0, 1], FLT_MAX),           # origin inside the box (negative entry)
+        ([0, 273, -800], 0, [0, 0, 1], FLT_MAX),            # origin on a slab with d = 0 there: 0*inf = NaN
+        ([278, 0, 100], 0, [1, 0, 0], FLT_MAX),             # grazing along the floor plane
+        ([278, 273, 100], 0, [0, 1, 0], FLT_MAX),           # axis aligned
+        ([278, 273, 100], 0, [0, -1, 0], FLT_MAX),
+        ([278, 273, 100], 0, [-0.0, -1, -0.0], FLT_MAX),    # negative zeros: inv_d = -inf
+        ([278, 273, 100], 0, [np.nan, 0, 1], FLT_MAX),      # NaN direction
+        ([278, 273, 100], 0, [0, 0, 0], FLT_MAX),           # zero direction
+        ([278, 273, 100], 0, [0, 0, 1], inf),               # infinite range
+        ([278, 273, 100], inf, [0, 0, 1], inf),             # t_min = inf: distance < t_min break
+        ([130, 165, 65], 0, [0.6, 0.0, 0.8], FLT_MAX),      # starts on a vertex of the short block
+        ([552.8, 0, 0], 0, [-0.70710677, 0.70710677, 0], FLT_MAX),  # from a corner along a wall
+    ]
+    ro = np.array([r[0] + [r[1]] for r in rays], np.float32)
+    rd = np.array([r[2] + [r[3]] for r in rays], np.float32)
+    want = oracle_cornell.trace_closest(ro, rd)
+    got = gpu_cornell.trace(ro, rd)
+    assert_hits_equal(got, want)
+    assert np.array_equal(gpu_cornell.trace(ro, rd, is_vis_ray=True), oracle_cornell.trace_any(ro, rd))
+    assert want["tri_id"][0] != rt.GIGL_MISS and want["tri_id"][1] == rt.GIGL_MISS
+
+
+def test_shared_edge_and_vertex_ties(gpu_cornell, oracle_cornell, cornell):
+    """Rays aimed exactly at shared edges / vertices of quads: the reference's tie behaviour
+    (first-tested triangle wins exact distance ties, KdTree.hpp:323-332 with the strict `<` of
+    RTBase.cpp:167) must come out the same."""
+    V, T = cornell["verts"], cornell["tris"]
+    cam = np.array(S.CAM_POS, np.float32)
+    targets = []
+    for q in range(len(T) // 2):
+        a, b = T[2 * q], T[2 * q + 1]
+        c0, c1, c2, c3 = V[a[0]], V[a[1]], V[a[2]], V[b[2]]
+        targets += [c0, c1, c2, c3, (c0 + c2) * np.float32(0.5), (c0 + c1) * np.float32(0.5),
+                    c0 + (c2 - c0) * np.float32(0.25)]
+    targets = np.array(targets, np.float32)
+    d = targets - cam
+    d = d * (np.float32(1.0) / np.sqrt((d * d).sum(1, dtype=np.float32)))[:, None]
+    ro = np.concatenate([np.tile(cam, (len(d), 1)), np.zeros((len(d), 1), np.float32)], 1)
+    rd = np.concatenate([d, np.full((len(d), 1), FLT_MAX, np.float32)], 1)
+    assert_hits_equal(gpu_cornell.trace(ro, rd), oracle_cornell.trace_closest(ro, rd))
+
+
+def test_trace_one(gpu_cornell, oracle_cornell):
+    hit, rec, nrm = gpu_cornell.trace_one([278, 273, -800], [0, 0, 1])
+    want = oracle_cornell.trace_closest(np.array([[278, 273, -800, 0]], np.float32),
+                                        np.array([[0, 0, 1, FLT_MAX]], np.float32))[0]
+    assert hit and rec["tri_id"] == want["tri_id"] and rec["t"] == want["t"]
+    assert abs(float(np.linalg.norm(nrm)) - 1.0) < 1e-6
+    hit, rec, _ = gpu_cornell.trace_one([278, 273, -800], [0, 0, -1])
+    assert not hit and rec["tri_id"] == rt.GIGL_MISS
+
+
+def test_sample_density_and_transmittance(density, fog_box):
+    torch = pytest.importorskip("torch")
+    fog_o = O.Fog(density, fog_box, np.float32(S.ABS_K) + np.float32(S.SCA_K))
+    fog_g = rt.FogVolume(density, fog_box, S.ABS_K, S.SCA_K)
+    rng = np.random.default_rng(7)
+    lo, hi = fog_box[:3] - 30, fog_box[3:] + 30
+    pos = (lo + (hi - lo) * rng.random((20000, 3))).astype(np.float32)
+    pos[:8] = [fog_box[:3], fog_box[3:], (fog_box[:3] + fog_box[3:]) / 2, fog_box[:3] - 1e-3,
+               fog_box[3:] + 1e-3, [0, 0, -1], [559, 548.8, 559.2], [279.5, 274.4, 279.1]]
+    got = fog_g.sample_density(pos)
+    want = np.array([O.sample_density(fog_o, p) for p in pos], np.float32)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    # segments: random points to random "lights", some outside the fog box, some degenerate
+    n = 50000
+    p = (lo + (hi - lo) * rng.random((n, 3))).astype(np.float32)
+    L = (lo + (hi - lo) * rng.random((n, 3))).astype(np.float32)
+    v = L - p
+    dsq = (v * v).sum(1, dtype=np.float32)
+    w = v * (np.float32(1.0) / np.sqrt(dsq))[:, None]
+    w[:16, 0] = 0.0   # axis-parallel components -> inf reciprocals in intersectBBox
+    seg_p = np.concatenate([p, np.zeros((n, 1), np.float32)], 1)
+    seg_d = np.concatenate([w, dsq[:, None]], 1).astype(np.float32)
+    tp = torch.from_numpy(seg_p).cuda()
+    td = torch.from_numpy(seg_d).cuda()
+    out = torch.zeros(n, dtype=torch.float32, device="cuda:0")
+    fog_g.transmittance_device(tp.data_ptr(), td.data_ptr(), n, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    want = O.transmittance(fog_o, seg_p, seg_d, n_threads=4)
+    rel = np.abs(got.astype(np.float64) - want) / np.maximum(np.abs(want), 1e-30)
+    assert float(rel.max()) <= REL_TOL
+    assert (want < 0.999).mean() > 0.3   # the batch does exercise the march
+    fog_g.close()
+
+
+def test_shadow_batch_cornell(gpu_cornell, oracle_cornell, cornell_cam, density, fog_box):
+    """Config 2 second half + config 5 on a subsample: primary hit points x lights."""
+    torch = pytest.importorskip("torch")
+    # every 37th pixel of rows 300..700 (hits and misses both present), 150 light positions
+    pix = np.arange(300 * 1024, 700 * 1024, 37, dtype=np.uint64)
+    ro = np.concatenate([O.primary_rays(cornell_cam, 1024, int(p), 1)[0] for p in pix[:4000]])
+    rd = np.concatenate([O.primary_rays(cornell_cam, 1024, int(p), 1)[1] for p in pix[:4000]])
+    # a few guaranteed misses
+    rd[:5, :3] = [0, 0, -1]
+    hits = oracle_cornell.trace_closest(ro, rd)
+    rng = np.random.default_rng(11)
+    lights = np.stack([rng.uniform(5, 550, 150), rng.uniform(5, 545, 150), rng.uniform(5, 555, 150)], 1).astype(np.float32)
+    lights[0] = S.PRIM_PL_POS
+    fog_o = O.Fog(density, fog_box, np.float32(S.ABS_K) + np.float32(S.SCA_K))
+    fog_g = rt.FogVolume(density, fog_box, S.ABS_K, S.SCA_K)
+    want_occ, want_tr = oracle_cornell.shadow_batch(ro, rd, hits, lights, fog=fog_o, want_transm=True, n_threads=4)
+    n_pts, nl = len(ro), len(lights)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    d_o, d_d, d_l = t(ro), t(rd), t(lights)
+    d_h = torch.from_numpy(hits.view(np.int32).reshape(-1, 4).copy()).cuda()
+    bits = torch.zeros((n_pts * nl + 63) // 64, dtype=torch.int64, device="cuda:0")
+    tr = torch.zeros(n_pts * nl, dtype=torch.float32, device="cuda:0")
+    gpu_cornell.shadow_batch_device(d_o.data_ptr(), d_d.data_ptr(), d_h.data_ptr(), n_pts, d_l.data_ptr(), nl,
+                                    bits.data_ptr(), fog=fog_g, transm_ptr=tr.data_ptr(),
+                                    stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = rt.unpack_bits(bits.cpu().numpy().view(np.uint64), n_pts * nl).reshape(n_pts, nl)
+    missed = hits["tri_id"] == rt.GIGL_MISS
+    assert missed.sum() >= 5
+    want01 = np.where(want_occ == 0xFF, 0, want_occ)
+    assert np.array_equal(got, want01)
+    assert 0.05 < want01[~missed].mean() < 0.95
+    got_tr = tr.cpu().numpy().reshape(n_pts, nl)
+    rel = np.abs(got_tr.astype(np.float64) - want_tr) / np.maximum(np.abs(want_tr), 1e-30)
+    assert float(rel.max()) <= REL_TOL
+    fog_g.close()
