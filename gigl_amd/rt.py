@@ -48,6 +48,14 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("HIP engine missing: %s (build with __graft_entry__.build() or "
                                "`make -C gigl_amd/csrc`)" % LIB_PATH)
+        # PyTorch-ROCm wheels bundle their own libamdhip64.so.7 / libhsa-runtime64.so.1 under the
+        # same sonames as /opt/rocm.  Whichever loads first serves the whole process, and torch
+        # cannot initialise on top of the system copy, so in a process that uses torch for device
+        # memory torch must come first.  (A C++ host never meets this: it links /opt/rocm only.)
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         vp, u32, u64, i, f = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_float
         L.gigl_last_error.restype = C.c_char_p
