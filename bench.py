@@ -1,0 +1,276 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the ray-query hot path on MI355X.
+
+Workload (BASELINE.json configs[2], the one the 1 Grays/s target is quoted on): the synthetic
+tessellated Cornell scene S(158) = 998,560 triangles, and 2^24 incoherent cosine-weighted
+diffuse-bounce rays per GPU, traced closest-hit through the reference's k-d tree semantics.
+A "step" is one closest-hit pass over the whole ray batch, rays and tree resident in HBM.
+
+N > 1 (one process per GPU, launched by torch.distributed.run): the tree is replicated, every
+rank traces its own 2^24-ray shard (weak scaling: N=8 is configs[3]'s 128M rays) and the 16-byte
+hit records are gathered to rank 0 over RCCL, pipelined in chunks behind the traversal.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--tess", type=int, default=158, help="k of scene S(k); 158 -> 998,560 triangles")
+    ap.add_argument("--rays-log2", type=int, default=24, help="rays per GPU = 2^this")
+    ap.add_argument("--chunks", type=int, default=4, help="gather pipeline depth for N > 1")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the RCCL gather of hit records")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--extras", action="store_true", help="also time any-hit and the Cornell configs (N=1)")
+    ap.add_argument("--opt", action="append", default=[], help="engine option name=value (gigl_set_option)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+    import torch
+    import torch.distributed as dist
+    from gigl_amd import rt, scene_io as S, synth
+
+    n_dev = torch.cuda.device_count()
+    dev_index = local_rank % max(n_dev, 1)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    backend = os.environ.get("GIGL_BENCH_BACKEND", "nccl")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        rt.set_option(k, int(v))
+
+    # ---- inputs (not timed): scene, tree, rays ----
+    t0 = time.time()
+    cv, ct, _, _ = S.load_obj(os.path.join(ROOT, "tests", "golden", "cornell_box.obj"))
+    V, T = synth.tessellate(cv, ct, args.tess)
+    scene = rt.Scene(V, T, device=dev_index, **S.KD_PARAMS)
+    st = scene.stats()
+    n = 1 << args.rays_log2
+    ro, rd = synth.bounce_rays(V, T, n, synth.RAY_SEED_16M if world == 1 else synth.RAY_SEED_128M,
+                               first=rank * n)
+    d_o = torch.from_numpy(ro).to(device)
+    d_d = torch.from_numpy(rd).to(device)
+    d_hits = torch.empty((n, 4), dtype=torch.int32, device=device)
+    setup_s = time.time() - t0
+    stream = torch.cuda.current_stream()
+    sh = stream.cuda_stream
+
+    gather = world > 1 and not args.no_gather
+    chunks = max(1, args.chunks) if gather else 1
+    bounds = [(i * n) // chunks for i in range(chunks + 1)]
+    comm_stream = torch.cuda.Stream(device=device) if gather else None
+    gathered = None
+    if gather and rank == 0:
+        gathered = [torch.empty((n, 4), dtype=torch.int32, device=device) for _ in range(world)]
+    host_gather = gather and backend != "nccl"
+
+    def step():
+        if not gather:
+            scene.trace_closest_device(d_o.data_ptr(), d_d.data_ptr(), n, d_hits.data_ptr(), sh)
+            return
+        works = []
+        for c in range(chunks):
+            lo, hi = bounds[c], bounds[c + 1]
+            scene.trace_closest_device(d_o[lo:hi].data_ptr(), d_d[lo:hi].data_ptr(), hi - lo,
+                                       d_hits[lo:hi].data_ptr(), sh)
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            with torch.cuda.stream(comm_stream):
+                comm_stream.wait_event(ev)
+                src = d_hits[lo:hi]
+                if host_gather:   # rehearsal backend (gloo): through host memory
+                    src_h = src.cpu()
+                    dst = [torch.empty_like(src_h) for _ in range(world)] if rank == 0 else None
+                    dist.gather(src_h, dst, dst=0)
+                else:
+                    dst = [g[lo:hi] for g in gathered] if rank == 0 else None
+                    works.append(dist.gather(src, dst, dst=0, async_op=True))
+        for w in works:
+            w.wait()
+        stream.wait_stream(comm_stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    t_start = time.perf_counter()
+    for i in range(args.steps):
+        ev0[i].record(stream)
+        step()
+        ev1[i].record(stream)
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    kern_ms = [a.elapsed_time(b) for a, b in zip(ev0, ev1)]
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = elapsed * 1e3 / args.steps
+    total_rays = n * world * args.steps
+    value = total_rays / elapsed / 1e6
+
+    out = None
+    if rank == 0:
+        hits = d_hits.cpu().numpy().view(rt.HIT_DTYPE).reshape(-1)
+        # size-independent sanity at full size: every reported hit lies inside its ray's range
+        hit_mask = hits["tri_id"] != rt.GIGL_MISS
+        assert (hits["tri_id"][hit_mask] < len(T)).all() and (hits["t"][hit_mask] > 0).all()
+        cpu = None
+        parity = None
+        bytes_per_ray = None
+        mean_nodes = mean_tris = None
+        if not args.no_cpu_baseline and world == 1:
+            from oracle import oracle_py as O
+            ora = O.OracleScene(V, T, **S.KD_PARAMS)
+            cores = min(16, os.cpu_count() or 1)
+            n1 = min(n, 1 << 18)
+            t1 = time.perf_counter()
+            ora.trace_closest(ro[:n1], rd[:n1], n_threads=1)
+            cpu1 = n1 / (time.perf_counter() - t1) / 1e6
+            nm = min(n, 1 << 21)
+            t1 = time.perf_counter()
+            want, cnt = ora.trace_closest(ro[:nm], rd[:nm], counters=True, n_threads=cores)
+            cpum = nm / (time.perf_counter() - t1) / 1e6
+            got = hits[:nm]
+            id_mis = int((got["tri_id"] != want["tri_id"]).sum())
+            same = got["tri_id"] == want["tri_id"]
+            rel = lambda k: float((np.abs(got[k][same].astype(np.float64) - want[k][same]) /
+                                   np.maximum(np.abs(want[k][same].astype(np.float64)), 1e-30)).max(initial=0.0))
+            parity = {"rays_checked": int(nm), "id_mismatches": id_mis, "max_rel_err_t": rel("t"),
+                      "max_rel_err_u": rel("u"), "max_rel_err_v": rel("v")}
+            mean_nodes, mean_tris = float(cnt[:, 0].mean()), float(cnt[:, 1].mean())
+            # 32 B ray in + 16 B hit out + 8 B per node visited + 56 B per triangle test
+            bytes_per_ray = 32.0 + 16.0 + 8.0 * mean_nodes + 56.0 * mean_tris
+            cpu = {"value": round(cpum, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+                   "sample": "first 2^%d rays of the same batch, OpenMP schedule(dynamic) over rays; "
+                             "single-thread on the first 2^%d rays: %.4f Mrays/s"
+                             % (int(np.log2(nm)), int(np.log2(n1)), cpu1),
+                   "single_thread_mrays_s": round(cpu1, 4)}
+        if bytes_per_ray is None:
+            # counters measured on the N=1 run of the same workload (profiles/); used when the CPU leg is skipped
+            bytes_per_ray = 32.0 + 16.0 + 8.0 * 61.06 + 56.0 * 7.72
+        k_ms = float(np.mean(kern_ms))
+        achieved = bytes_per_ray * n / (k_ms * 1e-3) / 1e9   # per GPU: one launch sequence over this rank's rays
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get("trace_closest_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mrays/s (incoherent closest-hit)", "value": round(value, 3), "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "S(%d) tessellated Cornell scene, %d triangles, k-d tree %d nodes depth %d; "
+                                   "2^%d incoherent diffuse-bounce closest-hit rays per GPU%s"
+                                   % (args.tess, len(T), st.n_nodes, st.actual_depth, args.rays_log2,
+                                      ("; hit records gathered to rank 0 over %s in %d chunks" % (backend, chunks))
+                                      if gather else ""),
+                       "triangles": int(len(T)), "rays_per_gpu": int(n), "tree_build_ms": round(st.build_ms, 1),
+                       "tree_device_bytes": int(st.device_bytes), "setup_s": round(setup_s, 1)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "kernel": "trace_kernel<closest>", "kernel_ms": round(k_ms, 4),
+                         "algorithmic_bytes_per_ray": round(bytes_per_ray, 2),
+                         "mean_nodes_visited": mean_nodes, "mean_triangle_tests": mean_tris},
+            "cpu_baseline": cpu,
+            "parity": parity,
+        }
+        if args.extras and world == 1:
+            out["extras"] = extras(torch, rt, S, scene, d_o, d_d, n, device)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    scene.close()
+
+
+def extras(torch, rt, S, scene, d_o, d_d, n, device):
+    """Untimed-by-the-driver side measurements: any-hit on the same batch, Cornell configs 2 and 5."""
+    from oracle import oracle_py as O
+    res = {}
+    sh = torch.cuda.current_stream().cuda_stream
+
+    def timeit(fn, reps=3):
+        fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps
+
+    bits = torch.zeros((n + 63) // 64, dtype=torch.int64, device=device)
+    ms = timeit(lambda: scene.trace_any_device(d_o.data_ptr(), d_d.data_ptr(), n, bits.data_ptr(), sh))
+    res["any_hit_same_batch_mrays_s"] = round(n / ms / 1e3, 2)
+    # Cornell: 1024^2 primary + x150 shadow (+ transmittance)
+    cv, ct, _, _ = S.load_obj(os.path.join(ROOT, "tests", "golden", "cornell_box.obj"))
+    cs = rt.Scene(cv, ct, device=device.index, **S.KD_PARAMS)
+    cam = rt.camera_setup(S.CAM_POS, S.CAM_DIR, S.CAM_UP, S.CAM_HFOV, 1024, 1024)
+    npix = 1024 * 1024
+    po = torch.empty((npix, 4), dtype=torch.float32, device=device)
+    pd = torch.empty((npix, 4), dtype=torch.float32, device=device)
+    ph = torch.empty((npix, 4), dtype=torch.int32, device=device)
+    cs.gen_primary_rays_device(cam, 1024, 0, npix, po.data_ptr(), pd.data_ptr(), sh)
+    ms = timeit(lambda: cs.trace_primary_device(cam, 1024, 0, npix, ph.data_ptr(), sh))
+    res["cornell_primary_mrays_s"] = round(npix / ms / 1e3, 2)
+    rng = np.random.default_rng(5)
+    lights = np.stack([rng.uniform(5, 550, 150), rng.uniform(5, 545, 150), rng.uniform(5, 555, 150)], 1).astype(np.float32)
+    dl = torch.from_numpy(lights).to(device)
+    npair = npix * 150
+    sb = torch.zeros((npair + 63) // 64, dtype=torch.int64, device=device)
+    ms = timeit(lambda: cs.shadow_batch_device(po.data_ptr(), pd.data_ptr(), ph.data_ptr(), npix, dl.data_ptr(), 150,
+                                               sb.data_ptr(), stream=sh), reps=2)
+    nhit = int((ph[:, 0] != -1).sum().item())
+    res["cornell_shadow_pairs"] = nhit * 150
+    res["cornell_shadow_mrays_s"] = round(nhit * 150 / ms / 1e3, 2)
+    dens = O.make_density((64, 64, 64), 12.0, 1.0)
+    box = cs.bbox().copy()
+    box[4] = min(box[4], np.float32(S.MAX_FOG_HEIGHT))
+    fog = rt.FogVolume(dens, box, S.ABS_K, S.SCA_K)
+    tr = torch.empty(npair, dtype=torch.float32, device=device)
+    ms = timeit(lambda: cs.shadow_batch_device(po.data_ptr(), pd.data_ptr(), ph.data_ptr(), npix, dl.data_ptr(), 150,
+                                               None, fog=fog, transm_ptr=tr.data_ptr(), stream=sh), reps=2)
+    res["cornell_transmittance_msegments_s"] = round(nhit * 150 / ms / 1e3, 2)
+    fog.close()
+    cs.close()
+    return res
+
+
+if __name__ == "__main__":
+    main()
