@@ -100,6 +100,7 @@ struct TraceParams {
     unsigned spill_stride;
     int refill_thresh;
     int any_atomic;
+    unsigned chunk;   // rays a wave takes from the global counter per atomic (multiple of 64)
     // GEN 0: explicit rays
     const float4* o_tmin;
     const float4* d_tmax;
@@ -181,13 +182,25 @@ __device__ __forceinline__ bool fetch_ray(const TraceParams& P, unsigned idx, Ra
     }
 }
 
+// Flattened triangle record: 3 float4 = (p0.xyz, e0.x) (e0.yz, e1.xy) (e1.z, mat, -, -).
+struct TriRec { float4 a, b; float e1z; };
+
+// All three loads are issued before any use: one memory round trip per triangle (left to itself
+// the compiler sinks the p0 load below the det != 0 test, which makes it two).
+__device__ __forceinline__ TriRec load_tri(const float4* __restrict__ tris, unsigned id) {
+    TriRec t;
+    const float4* p = tris + 3 * (size_t)id;
+    t.a = p[0]; t.b = p[1]; t.e1z = p[2].x;
+    asm volatile("" : "+v"(t.a.x), "+v"(t.a.y), "+v"(t.a.z), "+v"(t.a.w));
+    return t;
+}
+
 // Triangle::intersect, RTBase.cpp:150-177.  Edges are stored precomputed (pt1-pt0, pt2-pt0 are
 // the same float subtractions the reference performs per test).
-__device__ __forceinline__ bool tri_test(const float4* __restrict__ tris, unsigned id, const RayReg& r,
-                                         float& best_t, float& best_u, float& best_v, unsigned& best_id) {
-    const float4 a = tris[3 * (size_t)id], b = tris[3 * (size_t)id + 1];
-    const float e1z = tris[3 * (size_t)id + 2].x;
-    const float p0x = a.x, p0y = a.y, p0z = a.z, e0x = a.w, e0y = b.x, e0z = b.y, e1x = b.z, e1y = b.w;
+__device__ __forceinline__ bool tri_test(const TriRec& T, unsigned id, const RayReg& r, float& best_t,
+                                         float& best_u, float& best_v, unsigned& best_id) {
+    const float p0x = T.a.x, p0y = T.a.y, p0z = T.a.z, e0x = T.a.w, e0y = T.b.x, e0z = T.b.y, e1x = T.b.z,
+                e1y = T.b.w, e1z = T.e1z;
     const float pvx = r.dy * e1z - e1y * r.dz, pvy = r.dz * e1x - e1z * r.dx, pvz = r.dx * e1y - e1x * r.dy;
     const float det = (e0x * pvx + e0y * pvy) + e0z * pvz;
     if (det != 0.0f) {
@@ -207,6 +220,23 @@ __device__ __forceinline__ bool tri_test(const float4* __restrict__ tris, unsign
     return false;
 }
 
+// Spill-area accesses are opaque to the optimizer on purpose: merged with the LDS path they
+// turn every stack access into a flat_* instruction.
+__device__ __forceinline__ void spill_store(uint2* p, uint2 e) {
+    asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(e) : "memory");
+}
+__device__ __forceinline__ uint2 spill_load(const uint2* p) {
+    uint2 e;
+    asm volatile("global_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(e) : "v"(p) : "memory");
+    return e;
+}
+
+// Device node encoding (same topology and numbering as the reference's m_nodes, KdTree.h:22-65):
+//   interior: w0 = split_pos, w1 = above_child << 3 | axis << 1
+//   leaf:     w1 bit0 = 1, bits 1-2 = kind
+//             kind 0: empty          kind 1: one prim, w0 = id
+//             kind 2: two prims, w0 = id0, w1 >> 3 = id1 (saves the m_leaf_prim_ids round trip)
+//             kind 3: n >= 3 prims, w0 = offset into leaf_ids, w1 >> 3 = n
 template <bool ANY, int GEN, int STACK_N, int BLOCK>
 __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
     __shared__ uint2 s_stack[STACK_N * BLOCK];
@@ -222,6 +252,8 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
     unsigned node = 0, ray_idx = 0;
     int sp = -1;
     bool have_ray = false, pool_empty = false;
+    // wave-local slice of the ray index space, refilled CHUNK rays at a time with one atomic
+    unsigned pool_next = 0, pool_end = 0;
     // any-hit "group" mode: a wave owns 64 consecutive rays and writes their bits with one store
     unsigned group_base = kMiss;
     bool occ = false;
@@ -231,11 +263,11 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
         ++sp;
         const uint2 e = make_uint2(__float_as_uint(t_split), id);
         if (STACK_N >= 32 || sp < STACK_N) my_stack[sp * BLOCK] = e;
-        else my_spill[(size_t)(sp - STACK_N) * P.spill_stride] = e;
+        else spill_store(my_spill + (size_t)(sp - STACK_N) * P.spill_stride, e);
     };
     auto peek = [&](int k) -> uint2 {
         if (STACK_N >= 32 || k < STACK_N) return my_stack[k * BLOCK];
-        return my_spill[(size_t)(k - STACK_N) * P.spill_stride];
+        return spill_load(my_spill + (size_t)(k - STACK_N) * P.spill_stride);
     };
     auto finish = [&](bool hit) {
         if (ANY) {
@@ -257,34 +289,44 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
                 const unsigned long long m = __ballot(occ);
                 if (group_base != kMiss && lane == 0) P.bits[group_base >> 6] = m;
                 occ = false;
+                group_base = kMiss;
             }
-            unsigned base = 0;
-            if (lane == 0) base = atomicAdd(P.counter, (unsigned)n_idle);
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (base >= P.n || P.n - base <= (unsigned)n_idle) pool_empty = true;
-            if (group_mode) group_base = base < P.n ? base : kMiss;
-            if (!have_ray) {
-                const unsigned rank = __popcll(idle & ((1ull << lane) - 1ull));
-                const unsigned idx = base + rank;
-                if (base < P.n && idx < P.n) {
-                    ray_idx = idx;
-                    best_t = FLT_MAX; best_u = 0.0f; best_v = 0.0f; best_id = kMiss;
-                    bool go = fetch_ray<GEN>(P, idx, r);
-                    if (go) {
-                        // KdTree.hpp:269-274
-                        float entr, exit;
-                        go = box_intersect(P.box, r, entr, exit);
+            if (pool_next == pool_end) {
+                unsigned base = 0;
+                if (lane == 0) base = atomicAdd(P.counter, P.chunk);
+                base = __builtin_amdgcn_readfirstlane(base);
+                pool_next = base < P.n ? base : P.n;
+                pool_end = (P.n - pool_next) < P.chunk ? P.n : pool_next + P.chunk;
+                if (pool_next == pool_end) pool_empty = true;
+            }
+            if (!pool_empty) {
+                const unsigned avail = pool_end - pool_next;
+                const unsigned take = (unsigned)n_idle < avail ? (unsigned)n_idle : avail;
+                if (group_mode) group_base = pool_next;
+                if (!have_ray) {
+                    const unsigned rank = __popcll(idle & ((1ull << lane) - 1ull));
+                    if (rank < take) {
+                        const unsigned idx = pool_next + rank;
+                        ray_idx = idx;
+                        best_t = FLT_MAX; best_u = 0.0f; best_v = 0.0f; best_id = kMiss;
+                        bool go = fetch_ray<GEN>(P, idx, r);
                         if (go) {
-                            const float nmin = gmax(r.tmin, entr - rescaled_eps(entr));
-                            const float nmax = gmin(r.tmax, exit + rescaled_eps(exit));
-                            r.tmin = nmin; r.tmax = nmax;
-                            root_tmax = nmax;
-                            go = !(best_t < r.tmin);  // KdTree.hpp:280
+                            // KdTree.hpp:269-274
+                            float entr, exit;
+                            go = box_intersect(P.box, r, entr, exit);
+                            if (go) {
+                                const float nmin = gmax(r.tmin, entr - rescaled_eps(entr));
+                                const float nmax = gmin(r.tmax, exit + rescaled_eps(exit));
+                                r.tmin = nmin; r.tmax = nmax;
+                                root_tmax = nmax;
+                                go = !(best_t < r.tmin);  // KdTree.hpp:280
+                            }
                         }
+                        if (go) { have_ray = true; node = 0; sp = -1; }
+                        else finish(false);
                     }
-                    if (go) { have_ray = true; node = 0; sp = -1; }
-                    else finish(false);
                 }
+                pool_next = __builtin_amdgcn_readfirstlane(pool_next + take);
             }
         }
         if (__ballot(have_ray) == 0ull) {
@@ -316,14 +358,32 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
                 }
                 nd = P.nodes[node];
             }
-            // ---- leaf: KdTree.hpp:312-333 ----
-            const unsigned n_prims = nd.y >> 1;
+            // ---- leaf: KdTree.hpp:312-333.  Prims are tested in m_leaf_prim_ids order; loads are
+            // issued two triangles at a time, tests stay sequential. ----
+            const unsigned kind = (nd.y >> 1) & 3u;
             bool hit = false;
-            for (unsigned i = 0; i < n_prims; ++i) {
-                const unsigned id = (n_prims == 1u) ? nd.x : P.leaf_ids[nd.x + i];
-                if (tri_test(P.tris, id, r, best_t, best_u, best_v, best_id)) {
-                    hit = true;
-                    if (ANY) break;
+            if (kind != 0u) {
+                const unsigned n_prims = kind == 3u ? (nd.y >> 3) : kind;
+                for (unsigned i = 0; i < n_prims; i += 2) {
+                    unsigned id0, id1;
+                    const bool two = i + 1 < n_prims;
+                    if (kind == 3u) {
+                        id0 = P.leaf_ids[nd.x + i];
+                        id1 = two ? P.leaf_ids[nd.x + i + 1] : id0;
+                    } else {
+                        id0 = nd.x;
+                        id1 = two ? (nd.y >> 3) : id0;
+                    }
+                    const TriRec t0 = load_tri(P.tris, id0);
+                    const TriRec t1 = load_tri(P.tris, id1);
+                    if (tri_test(t0, id0, r, best_t, best_u, best_v, best_id)) {
+                        hit = true;
+                        if (ANY) break;
+                    }
+                    if (two && tri_test(t1, id1, r, best_t, best_u, best_v, best_id)) {
+                        hit = true;
+                        if (ANY) break;
+                    }
                 }
             }
             if (hit) {
@@ -484,9 +544,10 @@ int fail(int code, const std::string& msg) {
 
 struct Options {
     int stack_lds = 12;       // LDS entries per lane: 8, 12, 16 or 32
-    int refill_thresh = 16;   // idle lanes that trigger a refill (closest-hit / atomic any-hit)
+    int refill_thresh = 32;   // idle lanes that trigger a refill (closest-hit / atomic any-hit)
     int any_atomic = 0;       // 0: any-hit waves own 64 consecutive rays; 1: refill + atomicOr
     int blocks_per_cu = 0;    // 0: occupancy query
+    int chunk = 256;          // rays per work-counter atomic
 };
 Options g_opt;
 std::mutex g_opt_mu;
@@ -575,6 +636,7 @@ int launch_trace(const gigl_scene* s, TraceParams& P, hipStream_t st) {
     P.refill_thresh = (ANY && !P.any_atomic) ? 64 : opt.refill_thresh;
     if (P.refill_thresh < 1) P.refill_thresh = 1;
     if (P.refill_thresh > 64) P.refill_thresh = 64;
+    P.chunk = (unsigned)opt.chunk;
     if (ANY && P.any_atomic)
         if (hipMemsetAsync(P.bits, 0, ((size_t)P.n + 63) / 64 * 8, st) != hipSuccess)
             return fail(GIGL_ERR_HIP, "hipMemsetAsync(bits)");
@@ -639,6 +701,9 @@ int gigl_set_option(const char* name, int value) {
         g_opt.refill_thresh = value;
     } else if (k == "any_atomic") {
         g_opt.any_atomic = value ? 1 : 0;
+    } else if (k == "chunk") {
+        if (value < 64 || value > 65536 || value % 64) return fail(GIGL_ERR_INVALID, "chunk must be a multiple of 64 in 64..65536");
+        g_opt.chunk = value;
     } else if (k == "blocks_per_cu") {
         if (value < 0 || value > 8) return fail(GIGL_ERR_INVALID, "blocks_per_cu must be in 0..8");
         g_opt.blocks_per_cu = value;
@@ -739,9 +804,22 @@ int gigl_scene_create(const float* verts, uint32_t n_verts, const uint32_t* tris
     CREATE_TRY(hipMalloc((void**)&s->d_leaf_ids, nb_leaf));
     CREATE_TRY(hipMalloc((void**)&s->d_tris, nb_tris));
     CREATE_TRY(hipMalloc((void**)&s->d_one, 64));
-    if (!s->tree.nodes.empty())
-        CREATE_TRY(hipMemcpy(s->d_nodes, s->tree.nodes.data(), s->tree.nodes.size() * 8, hipMemcpyHostToDevice));
-    else {
+    if (!s->tree.nodes.empty()) {
+        // re-encode leaves for the device (see trace_kernel): the ids of 2-prim leaves move inline
+        std::vector<gigl::KdNode> dn(s->tree.nodes);
+        for (gigl::KdNode& nd : dn) {
+            if (!(nd.w1 & 1u)) continue;
+            const uint32_t np = nd.w1 >> 1;
+            if (np == 0) nd.w1 = 1u;
+            else if (np == 1) nd.w1 = 1u | (1u << 1);
+            else if (np == 2) {
+                const uint32_t off = nd.w0;
+                nd.w0 = s->tree.leaf_prim_ids[off];
+                nd.w1 = 1u | (2u << 1) | (s->tree.leaf_prim_ids[off + 1] << 3);
+            } else nd.w1 = 1u | (3u << 1) | (np << 3);
+        }
+        CREATE_TRY(hipMemcpy(s->d_nodes, dn.data(), dn.size() * 8, hipMemcpyHostToDevice));
+    } else {
         // empty scene: a single empty leaf (KdTree.hpp:9-12)
         const uint2 leaf = make_uint2(0u, 1u);
         CREATE_TRY(hipMemcpy(s->d_nodes, &leaf, 8, hipMemcpyHostToDevice));

@@ -126,7 +126,7 @@ def test_launch_options_do_not_change_results(s16, stack_lds, refill, any_atomic
         assert np.array_equal(occ.astype(bool), want["tri_id"] != rt.GIGL_MISS)
     finally:
         rt.set_option("stack_lds", 12)
-        rt.set_option("refill_thresh", 16)
+        rt.set_option("refill_thresh", 32)
         rt.set_option("any_atomic", 0)
 
 

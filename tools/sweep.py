@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Interleaved A/B timing of engine options on the bench workload (one process, one device).
+
+usage: python3 tools/sweep.py [--tess 158] [--rays-log2 24] [--rounds 3] name=v,name=v ...
+Each positional argument is one variant: a comma-separated list of gigl_set_option pairs, plus the
+pseudo-options `sorted=1` (rays pre-sorted on the host by origin cell + direction octant) and
+`any=1` (any-hit instead of closest-hit).
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def morton_sort_key(ro, rd, box, bits=10):
+    lo, hi = box[:3], box[3:]
+    q = np.clip(((ro[:, :3] - lo) / (hi - lo) * (1 << bits)).astype(np.int64), 0, (1 << bits) - 1)
+
+    def spread(v):
+        r = np.zeros_like(v)
+        for b in range(bits):
+            r |= ((v >> b) & 1) << (3 * b)
+        return r
+
+    m = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+    octant = (rd[:, 0] < 0).astype(np.int64) | ((rd[:, 1] < 0).astype(np.int64) << 1) | ((rd[:, 2] < 0).astype(np.int64) << 2)
+    return (octant << (3 * bits)) | m
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tess", type=int, default=158)
+    ap.add_argument("--rays-log2", type=int, default=24)
+    ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("variants", nargs="+")
+    a = ap.parse_args()
+    import torch
+    from gigl_amd import rt, scene_io as S, synth
+    dev = torch.device("cuda", 0)
+    cv, ct, _, _ = S.load_obj(os.path.join(ROOT, "tests", "golden", "cornell_box.obj"))
+    V, T = synth.tessellate(cv, ct, a.tess) if a.tess > 1 else (cv, ct)
+    scene = rt.Scene(V, T, device=0, **S.KD_PARAMS)
+    n = 1 << a.rays_log2
+    ro, rd = synth.bounce_rays(V, T, n, synth.RAY_SEED_16M)
+    d_o, d_d = torch.from_numpy(ro).to(dev), torch.from_numpy(rd).to(dev)
+    order = np.argsort(morton_sort_key(ro, rd, scene.bbox()), kind="stable")
+    s_o, s_d = torch.from_numpy(ro[order]).to(dev), torch.from_numpy(rd[order]).to(dev)
+    hits = torch.empty((n, 4), dtype=torch.int32, device=dev)
+    bits = torch.zeros((n + 63) // 64, dtype=torch.int64, device=dev)
+    sh = torch.cuda.current_stream().cuda_stream
+    defaults = {"stack_lds": 12, "refill_thresh": 32, "any_atomic": 0, "blocks_per_cu": 0, "chunk": 256}
+    res = {v: [] for v in a.variants}
+    ref_hits = None
+    for r in range(a.rounds + 1):
+        for v in a.variants:
+            opts = dict(defaults)
+            pseudo = {"sorted": 0, "any": 0}
+            for kv in v.split(","):
+                if not kv or kv == "base":
+                    continue
+                k, val = kv.split("=")
+                (pseudo if k in pseudo else opts)[k] = int(val)
+            for k, val in opts.items():
+                rt.set_option(k, val)
+            o, d = (s_o, s_d) if pseudo["sorted"] else (d_o, d_d)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            if pseudo["any"]:
+                scene.trace_any_device(o.data_ptr(), d.data_ptr(), n, bits.data_ptr(), sh)
+            else:
+                scene.trace_closest_device(o.data_ptr(), d.data_ptr(), n, hits.data_ptr(), sh)
+            e1.record()
+            torch.cuda.synchronize()
+            if r > 0:
+                res[v].append(e0.elapsed_time(e1))
+            if not pseudo["any"] and not pseudo["sorted"]:
+                h = hits.cpu().numpy()
+                if ref_hits is None:
+                    ref_hits = h.copy()
+                elif not np.array_equal(ref_hits, h):
+                    print("!! variant %s changed the results" % v, flush=True)
+    for v in a.variants:
+        t = np.array(res[v])
+        print("%-60s median %8.3f ms  min %8.3f ms  -> %8.1f Mrays/s" % (v, np.median(t), t.min(), n / np.median(t) / 1e3),
+              flush=True)
+    scene.close()
+
+
+if __name__ == "__main__":
+    main()
