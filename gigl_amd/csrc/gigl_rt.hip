@@ -101,6 +101,7 @@ struct TraceParams {
     int refill_thresh;
     int any_atomic;
     unsigned chunk;   // rays a wave takes from the global counter per atomic (multiple of 64)
+    int t_exit;       // T-phase repeats while at least this many lanes are still descending
     // GEN 0: explicit rays
     const float4* o_tmin;
     const float4* d_tmax;
@@ -116,6 +117,7 @@ struct TraceParams {
     // outputs
     uint4* hits;
     unsigned long long* bits;
+    unsigned long long* stats;   // STATS build only: 8 counters
 };
 
 // getPrimaryRay(x + 0.5, y + 0.5), Camera.cpp:65-68; normalize = v * (1/sqrt(dot)) (GLM).
@@ -237,7 +239,7 @@ __device__ __forceinline__ uint2 spill_load(const uint2* p) {
 //             kind 0: empty          kind 1: one prim, w0 = id
 //             kind 2: two prims, w0 = id0, w1 >> 3 = id1 (saves the m_leaf_prim_ids round trip)
 //             kind 3: n >= 3 prims, w0 = offset into leaf_ids, w1 >> 3 = n
-template <bool ANY, int GEN, int STACK_N, int BLOCK>
+template <bool ANY, int GEN, int STACK_N, int BLOCK, bool STATS = false>
 __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
     __shared__ uint2 s_stack[STACK_N * BLOCK];
     const unsigned tid = threadIdx.x;
@@ -281,10 +283,25 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
         have_ray = false;
     };
 
+    // Per-lane state machine.  A lane with a ray is either Traversing (nd is an interior node) or
+    // at a Leaf (nd is a leaf, leaf_i = next primitive to test).  Every round of the outer loop runs
+    // a T-phase (interior steps, repeated while at least t_exit lanes are still descending, so a
+    // few stragglers do not stall the lanes already waiting at leaves) and an L-phase (one pair of
+    // triangle tests per lane at a leaf).  Per ray the sequence of operations is the reference's.
+    uint2 nd = make_uint2(0u, 1u);
+    unsigned leaf_i = 0;
+    bool need_load = false;
+    const int t_exit = P.t_exit;
+    // STATS build only: wave-level round counts and lane-level work counts (tools/sweep.py stats=1)
+    unsigned st_rounds = 0, st_t_iters = 0, st_t_lanes = 0, st_l_rounds = 0, st_l_lanes = 0, st_refills = 0,
+             st_refill_lanes = 0, st_rays_lanes = 0;
+
     for (;;) {
         const unsigned long long idle = __ballot(!have_ray);
         const int n_idle = __popcll(idle);
+        if (STATS) { ++st_rounds; st_rays_lanes += 64 - n_idle; }
         if (n_idle >= P.refill_thresh && !pool_empty) {
+            if (STATS) { ++st_refills; st_refill_lanes += n_idle; }
             if (group_mode) {
                 const unsigned long long m = __ballot(occ);
                 if (group_base != kMiss && lane == 0) P.bits[group_base >> 6] = m;
@@ -322,7 +339,7 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
                                 go = !(best_t < r.tmin);  // KdTree.hpp:280
                             }
                         }
-                        if (go) { have_ray = true; node = 0; sp = -1; }
+                        if (go) { have_ray = true; node = 0; sp = -1; need_load = true; }
                         else finish(false);
                     }
                 }
@@ -333,10 +350,18 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
             if (pool_empty) break;
             continue;
         }
-        if (have_ray) {
-            // ---- descend to a leaf: KdTree.hpp:284-311 ----
-            uint2 nd = P.nodes[node];
-            while (!(nd.y & 1u)) {
+        if (have_ray && need_load) {
+            nd = P.nodes[node];
+            leaf_i = 0;
+            need_load = false;
+        }
+        // ---- T-phase: KdTree.hpp:284-311 ----
+        for (;;) {
+            const bool is_t = have_ray && !(nd.y & 1u);
+            const unsigned long long m_t = __ballot(is_t);
+            if (m_t == 0ull) break;
+            if (STATS) { ++st_t_iters; st_t_lanes += __popcll(m_t); }
+            if (is_t) {
                 const unsigned axis = (nd.y >> 1) & 3u;
                 const unsigned above = nd.y >> 3;
                 const float split = __uint_as_float(nd.x);
@@ -347,72 +372,87 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
                 const unsigned first = bottom_first ? node + 1u : above;
                 const unsigned second = bottom_first ? above : node + 1u;
                 const float t_split = (split - oa) * ia;
-                if (t_split > r.tmax || t_split <= 0.0f) {
-                    node = first;
-                } else if (t_split < r.tmin) {
-                    node = second;
-                } else {
+                const bool only_first = (t_split > r.tmax) || (t_split <= 0.0f);
+                const bool only_second = t_split < r.tmin;
+                if (!only_first && !only_second) {  // both children: the far one waits on the stack
                     push(t_split, second);
-                    node = first;
                     r.tmax = t_split + rescaled_eps(t_split);
                 }
+                node = (!only_first && only_second) ? second : first;
                 nd = P.nodes[node];
+                leaf_i = 0;
             }
-            // ---- leaf: KdTree.hpp:312-333.  Prims are tested in m_leaf_prim_ids order; loads are
-            // issued two triangles at a time, tests stay sequential. ----
+            if ((int)__popcll(m_t) < t_exit) break;
+        }
+        // ---- L-phase: KdTree.hpp:312-343.  Prims are tested in m_leaf_prim_ids order, two per
+        // round; both triangles' loads are issued before the first test. ----
+        if (STATS) {
+            const unsigned long long m_l = __ballot(have_ray && (nd.y & 1u));
+            if (m_l) { ++st_l_rounds; st_l_lanes += __popcll(m_l); }
+        }
+        if (have_ray && (nd.y & 1u)) {
             const unsigned kind = (nd.y >> 1) & 3u;
-            bool hit = false;
-            if (kind != 0u) {
-                const unsigned n_prims = kind == 3u ? (nd.y >> 3) : kind;
-                for (unsigned i = 0; i < n_prims; i += 2) {
-                    unsigned id0, id1;
-                    const bool two = i + 1 < n_prims;
-                    if (kind == 3u) {
-                        id0 = P.leaf_ids[nd.x + i];
-                        id1 = two ? P.leaf_ids[nd.x + i + 1] : id0;
-                    } else {
-                        id0 = nd.x;
-                        id1 = two ? (nd.y >> 3) : id0;
-                    }
-                    const TriRec t0 = load_tri(P.tris, id0);
-                    const TriRec t1 = load_tri(P.tris, id1);
-                    if (tri_test(t0, id0, r, best_t, best_u, best_v, best_id)) {
-                        hit = true;
-                        if (ANY) break;
-                    }
-                    if (two && tri_test(t1, id1, r, best_t, best_u, best_v, best_id)) {
-                        hit = true;
-                        if (ANY) break;
-                    }
-                }
-            }
-            if (hit) {
-                finish(true);
-            } else if (sp >= 0) {
-                // ---- pop: KdTree.hpp:334-339.  The reference stores (t_min, t_max, id); t_min is
-                // t_split - eps(t_split) (:305) and the stored t_max is always the t_max set when the
-                // entry below was pushed, t_split' + eps(t_split') (:310), or the root t_max for the
-                // bottom entry, so both are rebuilt from the stored t_split values.
-                const uint2 e = peek(sp);
-                const float ts = __uint_as_float(e.x);
-                node = e.y;
-                r.tmin = ts - rescaled_eps(ts);
-                if (sp > 0) {
-                    const float tb = __uint_as_float(peek(sp - 1).x);
-                    r.tmax = tb + rescaled_eps(tb);
+            const unsigned n_prims = kind == 3u ? (nd.y >> 3) : kind;
+            bool any_done = false;
+            if (leaf_i < n_prims) {
+                unsigned id0, id1;
+                const bool two = leaf_i + 1 < n_prims;
+                if (kind == 3u) {
+                    id0 = P.leaf_ids[nd.x + leaf_i];
+                    id1 = two ? P.leaf_ids[nd.x + leaf_i + 1] : id0;
                 } else {
-                    r.tmax = root_tmax;
+                    id0 = nd.x;
+                    id1 = two ? (nd.y >> 3) : id0;
                 }
-                --sp;
-                if (best_t < r.tmin) finish(false);  // KdTree.hpp:280
-            } else {
-                finish(false);
+                const TriRec t0 = load_tri(P.tris, id0);
+                const TriRec t1 = load_tri(P.tris, id1);
+                bool hit = tri_test(t0, id0, r, best_t, best_u, best_v, best_id);
+                if (!(ANY && hit) && two) hit = tri_test(t1, id1, r, best_t, best_u, best_v, best_id) || hit;
+                any_done = ANY && hit;
+                leaf_i += 2;
+            }
+            if (any_done) {
+                finish(true);
+            } else if (leaf_i >= n_prims) {
+                if (best_id != kMiss) {
+                    finish(true);  // closest hit inside this leaf's cell: KdTree.hpp:320,332
+                } else if (sp >= 0) {
+                    // ---- pop: KdTree.hpp:334-339.  The reference stores (t_min, t_max, id); t_min is
+                    // t_split - eps(t_split) (:305) and the stored t_max is always the t_max set when
+                    // the entry below was pushed, t_split' + eps(t_split') (:310), or the root t_max
+                    // for the bottom entry, so both are rebuilt from the stored t_split values.
+                    const uint2 e = peek(sp);
+                    const float ts = __uint_as_float(e.x);
+                    node = e.y;
+                    r.tmin = ts - rescaled_eps(ts);
+                    if (sp > 0) {
+                        const float tb = __uint_as_float(peek(sp - 1).x);
+                        r.tmax = tb + rescaled_eps(tb);
+                    } else {
+                        r.tmax = root_tmax;
+                    }
+                    --sp;
+                    if (best_t < r.tmin) finish(false);  // KdTree.hpp:280
+                    else need_load = true;
+                } else {
+                    finish(false);
+                }
             }
         }
     }
     if (group_mode) {
         const unsigned long long m = __ballot(occ);
         if (group_base != kMiss && lane == 0) P.bits[group_base >> 6] = m;
+    }
+    if (STATS && lane == 0 && P.stats) {
+        atomicAdd(P.stats + 0, (unsigned long long)st_rounds);
+        atomicAdd(P.stats + 1, (unsigned long long)st_t_iters);
+        atomicAdd(P.stats + 2, (unsigned long long)st_t_lanes);
+        atomicAdd(P.stats + 3, (unsigned long long)st_l_rounds);
+        atomicAdd(P.stats + 4, (unsigned long long)st_l_lanes);
+        atomicAdd(P.stats + 5, (unsigned long long)st_refills);
+        atomicAdd(P.stats + 6, (unsigned long long)st_refill_lanes);
+        atomicAdd(P.stats + 7, (unsigned long long)st_rays_lanes);
     }
 }
 
@@ -545,12 +585,16 @@ int fail(int code, const std::string& msg) {
 struct Options {
     int stack_lds = 12;       // LDS entries per lane: 8, 12, 16 or 32
     int refill_thresh = 32;   // idle lanes that trigger a refill (closest-hit / atomic any-hit)
-    int any_atomic = 0;       // 0: any-hit waves own 64 consecutive rays; 1: refill + atomicOr
+    int any_atomic = -1;      // 0: any-hit waves own 64 consecutive rays, one store per wave; 1: lane refill +
+                              // atomicOr; -1: choose by tree depth (deep trees have long-tailed rays)
     int blocks_per_cu = 0;    // 0: occupancy query
     int chunk = 256;          // rays per work-counter atomic
+    int t_exit = 16;          // see trace_kernel: T-phase exit threshold (1..64)
+    int stats = 0;            // 1: closest-hit launches run the instrumented build and keep 8 counters
 };
 Options g_opt;
 std::mutex g_opt_mu;
+unsigned long long g_last_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
 constexpr int kBlock = 256;
 constexpr unsigned kMaxRays = 0xF0000000u;
@@ -595,6 +639,7 @@ struct DeviceGuard {
 template <bool ANY, int GEN, int STACK_N>
 int launch_trace_t(const gigl_scene* s, TraceParams& P, const Options& opt, hipStream_t st) {
     auto kern = trace_kernel<ANY, GEN, STACK_N, kBlock>;
+    if (!ANY && GEN == 0 && STACK_N == 12 && opt.stats) kern = trace_kernel<ANY, GEN, 12, kBlock, true>;
     int per_cu = opt.blocks_per_cu;
     if (per_cu <= 0) {
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kBlock, 0));
@@ -613,8 +658,17 @@ int launch_trace_t(const gigl_scene* s, TraceParams& P, const Options& opt, hipS
     P.counter = (unsigned*)ws;
     P.spill = (uint2*)((char*)ws + 256);
     P.spill_stride = grid * kBlock;
+    P.stats = nullptr;
+    if (!ANY && GEN == 0 && STACK_N == 12 && opt.stats) {
+        P.stats = (unsigned long long*)((char*)ws + 128);
+    }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, st, P);
     hipError_t le = hipGetLastError();
+    if (P.stats && le == hipSuccess) {  // diagnostic path: synchronous read-back
+        std::lock_guard<std::mutex> lk(g_opt_mu);
+        (void)hipMemcpyAsync(g_last_stats, P.stats, sizeof(g_last_stats), hipMemcpyDeviceToHost, st);
+        (void)hipStreamSynchronize(st);
+    }
     hipError_t fe = hipFreeAsync(ws, st);
     if (le != hipSuccess) return fail(GIGL_ERR_HIP, std::string("trace kernel launch: ") + hipGetErrorString(le));
     if (fe != hipSuccess) return fail(GIGL_ERR_HIP, std::string("hipFreeAsync: ") + hipGetErrorString(fe));
@@ -632,11 +686,12 @@ int launch_trace(const gigl_scene* s, TraceParams& P, hipStream_t st) {
     P.leaf_ids = s->d_leaf_ids;
     P.tris = s->d_tris;
     P.box = s->box;
-    P.any_atomic = ANY ? opt.any_atomic : 0;
+    P.any_atomic = ANY ? (opt.any_atomic < 0 ? (s->tree.actual_depth > 20 ? 1 : 0) : opt.any_atomic) : 0;
     P.refill_thresh = (ANY && !P.any_atomic) ? 64 : opt.refill_thresh;
     if (P.refill_thresh < 1) P.refill_thresh = 1;
     if (P.refill_thresh > 64) P.refill_thresh = 64;
     P.chunk = (unsigned)opt.chunk;
+    P.t_exit = opt.t_exit;
     if (ANY && P.any_atomic)
         if (hipMemsetAsync(P.bits, 0, ((size_t)P.n + 63) / 64 * 8, st) != hipSuccess)
             return fail(GIGL_ERR_HIP, "hipMemsetAsync(bits)");
@@ -688,6 +743,13 @@ int gigl_device_count(int* count) {
     return GIGL_OK;
 }
 
+int gigl_debug_last_stats(uint64_t out[8]) {
+    if (!out) return fail(GIGL_ERR_INVALID, "out is NULL");
+    std::lock_guard<std::mutex> lk(g_opt_mu);
+    for (int i = 0; i < 8; ++i) out[i] = g_last_stats[i];
+    return GIGL_OK;
+}
+
 int gigl_set_option(const char* name, int value) {
     if (!name) return fail(GIGL_ERR_INVALID, "name is NULL");
     std::lock_guard<std::mutex> lk(g_opt_mu);
@@ -700,7 +762,13 @@ int gigl_set_option(const char* name, int value) {
         if (value < 1 || value > 64) return fail(GIGL_ERR_INVALID, "refill_thresh must be in 1..64");
         g_opt.refill_thresh = value;
     } else if (k == "any_atomic") {
-        g_opt.any_atomic = value ? 1 : 0;
+        if (value < -1 || value > 1) return fail(GIGL_ERR_INVALID, "any_atomic must be -1, 0 or 1");
+        g_opt.any_atomic = value;
+    } else if (k == "stats") {
+        g_opt.stats = value ? 1 : 0;
+    } else if (k == "t_exit") {
+        if (value < 1 || value > 64) return fail(GIGL_ERR_INVALID, "t_exit must be in 1..64");
+        g_opt.t_exit = value;
     } else if (k == "chunk") {
         if (value < 64 || value > 65536 || value % 64) return fail(GIGL_ERR_INVALID, "chunk must be a multiple of 64 in 64..65536");
         g_opt.chunk = value;

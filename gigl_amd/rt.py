@@ -24,7 +24,7 @@ SYMBOLS = [
     "gigl_trace_any_device", "gigl_trace_any", "gigl_trace_one", "gigl_camera_setup",
     "gigl_gen_primary_rays_device", "gigl_trace_primary_device", "gigl_shadow_batch_device", "gigl_fog_create",
     "gigl_fog_destroy", "gigl_transmittance_device", "gigl_sample_density", "gigl_debug_rescaled_eps",
-    "gigl_set_option",
+    "gigl_set_option", "gigl_debug_last_stats",
 ]
 
 
@@ -80,6 +80,7 @@ def lib():
         L.gigl_sample_density.argtypes = [vp, vp, u64, vp]
         L.gigl_debug_rescaled_eps.argtypes = [i, vp, u64, vp]
         L.gigl_set_option.argtypes = [C.c_char_p, i]
+        L.gigl_debug_last_stats.argtypes = [vp]
         for s in SYMBOLS:
             if s != "gigl_last_error":
                 getattr(L, s).restype = C.c_int
@@ -108,6 +109,14 @@ def device_count():
 
 def set_option(name, value):
     _check(lib().gigl_set_option(name.encode(), int(value)))
+
+
+def debug_last_stats():
+    out = np.zeros(8, np.uint64)
+    _check(lib().gigl_debug_last_stats(_p(out)))
+    names = ["rounds", "t_iters", "t_lane_steps", "l_rounds", "l_lane_rounds", "refills", "refill_lanes",
+             "ray_lane_rounds"]
+    return dict(zip(names, out.tolist()))
 
 
 def camera_setup(pos, direction, up, h_fov, res_x, res_y):

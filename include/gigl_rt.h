@@ -151,6 +151,11 @@ int gigl_sample_density(const gigl_fog* f, const float* pos, uint64_t n, float* 
  * exists so the parity tests can pin the device arithmetic of the traversal epsilon. */
 int gigl_debug_rescaled_eps(int device, const float* t, uint64_t n, float* out);
 
+/* Scheduling counters of the last closest-hit launch made with option "stats" = 1 (instrumented
+ * kernel build; diagnostic only): rounds, T-phase iterations, T lane-steps, L-phase rounds,
+ * L lane-rounds, refills, refilled lanes, sum over rounds of lanes holding a ray. */
+int gigl_debug_last_stats(uint64_t out[8]);
+
 /* Tuning knobs (process-wide; read at each launch).  Names and meaning in DESIGN.md. */
 int gigl_set_option(const char* name, int value);
 

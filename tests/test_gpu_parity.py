@@ -127,7 +127,7 @@ def test_launch_options_do_not_change_results(s16, stack_lds, refill, any_atomic
     finally:
         rt.set_option("stack_lds", 12)
         rt.set_option("refill_thresh", 32)
-        rt.set_option("any_atomic", 0)
+        rt.set_option("any_atomic", -1)
 
 
 def test_edge_cases(gpu_cornell, oracle_cornell):

@@ -52,13 +52,13 @@ def main():
     hits = torch.empty((n, 4), dtype=torch.int32, device=dev)
     bits = torch.zeros((n + 63) // 64, dtype=torch.int64, device=dev)
     sh = torch.cuda.current_stream().cuda_stream
-    defaults = {"stack_lds": 12, "refill_thresh": 32, "any_atomic": 0, "blocks_per_cu": 0, "chunk": 256}
+    defaults = {"stack_lds": 12, "refill_thresh": 32, "any_atomic": -1, "blocks_per_cu": 0, "chunk": 256, "t_exit": 16}
     res = {v: [] for v in a.variants}
     ref_hits = None
     for r in range(a.rounds + 1):
         for v in a.variants:
             opts = dict(defaults)
-            pseudo = {"sorted": 0, "any": 0}
+            pseudo = {"sorted": 0, "any": 0, "stats": 0}
             for kv in v.split(","):
                 if not kv or kv == "base":
                     continue
@@ -66,6 +66,7 @@ def main():
                 (pseudo if k in pseudo else opts)[k] = int(val)
             for k, val in opts.items():
                 rt.set_option(k, val)
+            rt.set_option("stats", pseudo["stats"])
             o, d = (s_o, s_d) if pseudo["sorted"] else (d_o, d_d)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -77,6 +78,12 @@ def main():
             torch.cuda.synchronize()
             if r > 0:
                 res[v].append(e0.elapsed_time(e1))
+            if pseudo["stats"] and r == a.rounds:
+                st = rt.debug_last_stats()
+                print(v, st, flush=True)
+                print("   T-phase lane utilisation %.3f, L-phase %.3f, lanes holding a ray %.3f, T iters/round %.2f" % (
+                    st["t_lane_steps"] / max(1, 64 * st["t_iters"]), st["l_lane_rounds"] / max(1, 64 * st["l_rounds"]),
+                    st["ray_lane_rounds"] / max(1, 64 * st["rounds"]), st["t_iters"] / max(1, st["rounds"])), flush=True)
             if not pseudo["any"] and not pseudo["sorted"]:
                 h = hits.cpu().numpy()
                 if ref_hits is None:
