@@ -1,0 +1,156 @@
+"""CPU: host-side logic of the engine — the tree builder against the oracle, the C ABI surface,
+error behaviour without a device, asset I/O and the synthetic input generators."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from gigl_amd import rt, scene_io as S, shard, synth
+from oracle import oracle_py as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "gigl_rt.h")).read()
+    declared = sorted(set(re.findall(r"\b(gigl_[a-z0-9_]+)\s*\(", hdr)))
+    assert declared, "no declarations found"
+    L = rt.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+    assert sorted(rt.SYMBOLS) == declared
+
+
+def test_product_library_does_not_reference_the_oracle():
+    # the product path must never route through the checker
+    blob = open(rt.LIB_PATH, "rb").read()
+    assert b"ora_scene" not in blob and b"gigl_oracle" not in blob
+    for fn in ("rt.py", "scene_io.py", "synth.py", "shard.py"):
+        src = open(os.path.join(ROOT, "gigl_amd", fn)).read()
+        assert "import oracle" not in src and "from oracle" not in src, fn
+
+
+@pytest.mark.parametrize("k", [1, 2, 5, 12])
+def test_builder_tree_equals_oracle_tree(cornell, k):
+    V, T = (cornell["verts"], cornell["tris"]) if k == 1 else synth.tessellate(cornell["verts"], cornell["tris"], k)
+    ps = rt.Scene(V, T, device=-1, **S.KD_PARAMS)
+    os_ = O.OracleScene(V, T, **S.KD_PARAMS)
+    nodes, leaf = ps.export_tree()
+    assert np.array_equal(nodes, os_.nodes())
+    assert np.array_equal(leaf, os_.leaf_prim_ids())
+    assert np.array_equal(ps.bbox(), os_.bbox())
+    st = ps.stats()
+    assert st.actual_depth == os_.depth and st.leaf_count == os_.leaf_count
+    assert abs(st.avg_prims_per_leaf - os_.avg_prims_per_leaf) < 1e-4
+    assert st.degenerate_split_guard_hit == 0
+    ps.close()
+
+
+def test_builder_other_parameters(cornell):
+    V, T = synth.tessellate(cornell["verts"], cornell["tris"], 6)
+    for params in (dict(inters_cost=80, trav_cost=1, max_depth=-1, min_num_prims=1, empty_bonus=0.5),
+                   dict(inters_cost=10, trav_cost=1, max_depth=5, min_num_prims=4, empty_bonus=0.0),
+                   dict(inters_cost=1, trav_cost=10, max_depth=30, min_num_prims=0, empty_bonus=0.25)):
+        ps = rt.Scene(V, T, device=-1, **params)
+        os_ = O.OracleScene(V, T, **params)
+        nodes, leaf = ps.export_tree()
+        assert np.array_equal(nodes, os_.nodes()) and np.array_equal(leaf, os_.leaf_prim_ids()), params
+        ps.close()
+
+
+def test_builder_is_independent_of_thread_count(cornell):
+    # subtrees near the root are built as parallel tasks and spliced in DFS order
+    V, T = synth.tessellate(cornell["verts"], cornell["tris"], 24)   # > spawn threshold
+    a = rt.Scene(V, T, device=-1, **S.KD_PARAMS)
+    os_ = O.OracleScene(V, T, **S.KD_PARAMS)
+    nodes, leaf = a.export_tree()
+    assert np.array_equal(nodes, os_.nodes()) and np.array_equal(leaf, os_.leaf_prim_ids())
+    a.close()
+
+
+def test_empty_and_degenerate_scenes():
+    e = rt.Scene(np.zeros((0, 3), np.float32), np.zeros((0, 4), np.uint32), device=-1)
+    assert e.stats().n_nodes == 0
+    e.close()
+    # one triangle; zero-area triangles; duplicated triangles
+    V = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 0]], np.float32)
+    for T in ([[0, 1, 2, 0]], [[0, 0, 0, 0], [0, 1, 2, 0]], [[0, 1, 2, 0]] * 40):
+        T = np.array(T, np.uint32)
+        ps = rt.Scene(V, T, device=-1, **S.KD_PARAMS)
+        os_ = O.OracleScene(V, T, **S.KD_PARAMS)
+        n, l = ps.export_tree()
+        assert np.array_equal(n, os_.nodes()) and np.array_equal(l, os_.leaf_prim_ids())
+        ps.close()
+
+
+def test_error_behaviour():
+    V = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    with pytest.raises(rt.GiglError) as ei:
+        rt.Scene(V, np.array([[0, 1, 7, 0]], np.uint32), device=-1)
+    assert ei.value.code == 4 and "index" in str(ei.value)
+    Vn = V.copy()
+    Vn[1, 1] = np.nan
+    with pytest.raises(rt.GiglError) as ei:
+        rt.Scene(Vn, np.array([[0, 1, 2, 0]], np.uint32), device=-1)
+    assert ei.value.code == 4
+    with pytest.raises(rt.GiglError) as ei:
+        rt.Scene(V, np.array([[0, 1, 2, 0]], np.uint32), max_depth=40, device=-1)
+    assert ei.value.code == 4 and "stack" in str(ei.value)
+    # a host-only scene refuses to trace: there is no CPU fallback
+    ps = rt.Scene(V, np.array([[0, 1, 2, 0]], np.uint32), device=-1)
+    with pytest.raises(rt.GiglError) as ei:
+        ps.trace(np.zeros((1, 4), np.float32), np.ones((1, 4), np.float32))
+    assert ei.value.code == 2
+    with pytest.raises(rt.GiglError):
+        rt.set_option("stack_lds", 13)
+    with pytest.raises(rt.GiglError):
+        rt.set_option("no_such_option", 1)
+    ps.close()
+
+
+def test_camera_matches_oracle(cornell_cam):
+    cam = rt.camera_setup(S.CAM_POS, S.CAM_DIR, S.CAM_UP, S.CAM_HFOV, S.WINDOW_RES, S.WINDOW_RES)
+    assert np.array_equal(cam.view(np.uint32), cornell_cam.view(np.uint32))
+
+
+def test_3dt_roundtrip(tmp_path, density):
+    p = str(tmp_path / "df.3dt")
+    S.write_3dt(p, density)
+    assert os.path.getsize(p) == 262156
+    back = S.read_3dt(p)
+    assert back.shape == (64, 64, 64) and np.array_equal(back, density)
+    f = np.arange(2 * 3 * 4, dtype=np.float32).reshape(4, 3, 2)
+    q = str(tmp_path / "pi.3dt")
+    S.write_3dt(q, f)
+    assert np.array_equal(S.read_3dt(q, np.float32), f)
+    with open(q, "ab") as fh:
+        fh.write(b"x")
+    with pytest.raises(ValueError):
+        S.read_3dt(q, np.float32)
+
+
+def test_synthetic_inputs(cornell):
+    V, T = synth.tessellate(cornell["verts"], cornell["tris"], 158 // 10)
+    assert len(T) == 20 * 15 * 15 * 2
+    V2, T2 = synth.tessellate(cornell["verts"], cornell["tris"], 15)
+    assert np.array_equal(V, V2) and np.array_equal(T, T2)          # deterministic
+    ro, rd = synth.bounce_rays(V, T, 5000, synth.RAY_SEED_16M)
+    ro2, rd2 = synth.bounce_rays(V, T, 3000, synth.RAY_SEED_16M, first=2000)
+    assert np.array_equal(ro[2000:], ro2) and np.array_equal(rd[2000:], rd2)   # counter based: shardable
+    ln = np.sqrt((rd[:, :3].astype(np.float64) ** 2).sum(1))
+    assert np.abs(ln - 1).max() < 1e-5
+    assert (ro[:, 3] == 0).all() and (rd[:, 3] == np.finfo(np.float32).max).all()
+    assert 20 * 158 * 158 * 2 == 998560 and 20 * 500 * 500 * 2 == 10_000_000
+
+
+def test_shard_ranges():
+    for n, w in ((10, 3), (1 << 24, 8), (7, 8), (0, 2)):
+        r = [shard.shard_range(n, w, k) for k in range(w)]
+        assert r[0][0] == 0 and r[-1][1] == n
+        assert all(r[i][1] == r[i + 1][0] for i in range(w - 1))
+        assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
+    assert shard.chunk_bounds(10, 4) == [0, 2, 5, 7, 10]
+    with pytest.raises(ValueError):
+        shard.shard_range(5, 2, 2)
