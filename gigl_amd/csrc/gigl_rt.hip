@@ -118,6 +118,7 @@ struct TraceParams {
     uint4* hits;
     unsigned long long* bits;
     unsigned long long* stats;   // STATS build only: 8 counters
+    float2* ranges;              // optional: the ray's (t_min, t_max) as KdTree::intersect leaves them
 };
 
 // getPrimaryRay(x + 0.5, y + 0.5), Camera.cpp:65-68; normalize = v * (1/sqrt(dot)) (GLM).
@@ -279,6 +280,7 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
             P.hits[ray_idx] = hit ? make_uint4(best_id, __float_as_uint(best_t), __float_as_uint(best_u),
                                                __float_as_uint(best_v))
                                   : make_uint4(kMiss, __float_as_uint(FLT_MAX), 0u, 0u);
+            if (P.ranges) P.ranges[ray_idx] = make_float2(r.tmin, r.tmax);
         }
         have_ray = false;
     };
@@ -1007,7 +1009,7 @@ int gigl_trace_any(const gigl_scene* s, const float* o_tmin, const float* d_tmax
 }
 
 int gigl_trace_one(const gigl_scene* s, const float o[3], const float d[3], float t_min, float t_max,
-                   int is_vis_ray, int* hit_out, gigl_hit* hit_rec, float normal_out[3]) {
+                   int is_vis_ray, int* hit_out, gigl_hit* hit_rec, float normal_out[3], float range_out[2]) {
     if (!s || !o || !d || !hit_out) return fail(GIGL_ERR_INVALID, "NULL argument");
     if (s->device == GIGL_DEVICE_NONE) return fail(GIGL_ERR_NO_DEVICE, "host-only scene: no device to trace on");
     // Scene::trace semantics on one ray: a closest-hit launch answers both modes (the bool of a
@@ -1018,9 +1020,18 @@ int gigl_trace_one(const gigl_scene* s, const float o[3], const float d[3], floa
     DeviceGuard g(s->device);
     HIP_TRY(hipMemcpy(s->d_one, ro, 16, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(s->d_one + 1, rd, 16, hipMemcpyHostToDevice));
-    int rc = gigl_trace_closest_device(s, s->d_one, s->d_one + 1, 1, (gigl_hit*)(s->d_one + 2), nullptr);
+    TraceParams P = {};
+    P.n = 1;
+    P.o_tmin = s->d_one;
+    P.d_tmax = s->d_one + 1;
+    P.hits = (uint4*)(s->d_one + 2);
+    P.ranges = (float2*)(s->d_one + 3);
+    int rc = launch_trace<false, 0>(s, P, nullptr);
     if (rc != GIGL_OK) return rc;
-    HIP_TRY(hipMemcpy(&h, s->d_one + 2, 16, hipMemcpyDeviceToHost));
+    float back[8];
+    HIP_TRY(hipMemcpy(back, s->d_one + 2, 32, hipMemcpyDeviceToHost));
+    memcpy(&h, back, 16);
+    if (range_out) { range_out[0] = back[4]; range_out[1] = back[5]; }
     *hit_out = h.tri_id != GIGL_MISS;
     if (hit_rec) *hit_rec = h;
     if (normal_out) {

@@ -1,0 +1,339 @@
+// gigl_host.hpp — C++ host-side mirror of the reference's RT interface over the C ABI.
+//
+// Header-only.  Same names, argument meaning and return conventions as the reference so that
+// its callers read unchanged:
+//   rt::Ray                 /root/reference/Source/RT/RTBase.h:81-105, RTBase.cpp:111-133
+//   BBox::IntDist           Source/Common/BBox.h:37-43
+//   Scene::trace / traceFog / sampleExtK / sampleScaK / getMajExtK / getScaAlbedo
+//                           Source/Common/Scene.h:33-47, Scene.cpp:209-251
+//   VPL (96 B, std140)      Source/VPL/PointLight.h:47-78, PointLight.cpp:15-22
+//   LightArray<VPL>         Source/VPL/LightArray.hpp:41-66
+//   rt::PhotonTracer::trace Source/RT/PhotonTracer.cpp:78-188
+// Every ray query and every density sample goes to the GPU through include/gigl_rt.h; nothing
+// here intersects or samples on the CPU.  The random numbers are taken from a caller-supplied
+// generator (the reference's UnitRNG is a global std::mt19937, Source/Common/Random.cpp:11-18).
+#pragma once
+
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <functional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/gigl_rt.h"
+
+namespace gigl_host {
+
+struct vec3 {
+    float x, y, z;
+};
+inline vec3 v3(float x, float y, float z) { return vec3{x, y, z}; }
+inline vec3 operator+(vec3 a, vec3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+inline vec3 operator-(vec3 a, vec3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline vec3 operator-(vec3 a) { return v3(-a.x, -a.y, -a.z); }
+inline vec3 operator*(vec3 a, vec3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+inline vec3 operator*(float s, vec3 a) { return v3(s * a.x, s * a.y, s * a.z); }
+inline vec3 operator*(vec3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+inline vec3 operator/(vec3 a, float s) { return v3(a.x / s, a.y / s, a.z / s); }
+// GLM 0.9.5.4 operation order (Source/Include/GLM/detail/func_geometric.inl:66-73, :224-227, :263-264)
+inline float dot(vec3 a, vec3 b) { vec3 t = a * b; return t.x + t.y + t.z; }
+inline vec3 cross(vec3 x, vec3 y) { return v3(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y); }
+inline float length(vec3 v) { return std::sqrt(v.x * v.x + v.y * v.y + v.z * v.z); }
+inline vec3 normalize(vec3 v) { return v * (1.0f / std::sqrt(v.x * v.x + v.y * v.y + v.z * v.z)); }
+
+// Source/Common/Constants.h
+constexpr float TWO_PI = 6.28318548f, PI = 3.14159274f, INV_PI = 0.318309873f;
+constexpr float RAY_OFFSET = 1E-4f, SURVIVAL_P_RR = 0.95f, MAX_FOG_HEIGHT = 548.8f, HG_G = 0.25f;
+constexpr int N_GI_BOUNCES = 3;
+
+struct GiglError : std::runtime_error {
+    int code;
+    GiglError(int c, const char* m) : std::runtime_error(std::string("gigl_rt: ") + m), code(c) {}
+};
+inline void check(int rc) {
+    if (rc != GIGL_OK) throw GiglError(rc, gigl_last_error());
+}
+
+// rt::PhongMaterial, Source/RT/RTBase.h:53-78 (48 B)
+struct PhongMaterial {
+    vec3 k_d; float pad; vec3 k_s; float n_s; vec3 k_e; float slack;
+    bool isEmissive() const { return k_e.x > 0.0f || k_e.y > 0.0f || k_e.z > 0.0f; }
+};
+
+namespace rt {
+struct Ray {
+    struct Intersection {
+        const PhongMaterial* material = nullptr;
+        float distance = FLT_MAX;
+        vec3 normal = {0.0f, 0.0f, 0.0f};
+    } inters;
+    vec3 o, d, inv_d;
+    float t_min, t_max;
+    Ray(vec3 origin, vec3 direction)
+        : o(origin), d(direction), inv_d{1.0f / direction.x, 1.0f / direction.y, 1.0f / direction.z}, t_min(0.0f),
+          t_max(FLT_MAX) {}
+    Ray(vec3 origin, vec3 direction, vec3 normal) : Ray(origin + RAY_OFFSET * normal, direction) {}
+    vec3 getPtAtDist(float t) const { return o + t * d; }
+    void setValidRange(float mn, float mx) { t_min = mn; t_max = mx; }
+};
+}  // namespace rt
+
+struct IntDist {  // BBox::IntDist
+    float entr = FLT_MAX, exit = -FLT_MAX;
+    explicit operator bool() const { return entr < FLT_MAX; }
+};
+
+// VPL, Source/VPL/PointLight.h:66-77
+struct VPL {
+    vec3 w_pos; uint32_t type; vec3 intensity; float sca_k; vec3 w_inc; uint32_t path_id;
+    vec3 w_norm; uint32_t pad1; vec3 k_d; uint32_t pad2; vec3 k_s; float n_s;
+};
+static_assert(sizeof(VPL) == 96, "std140 VPL record");
+
+struct LightArray {  // LightArray<VPL>, Source/VPL/LightArray.hpp
+    std::vector<VPL> pls;
+    int size() const { return (int)pls.size(); }
+    void clear() { pls.clear(); }
+    bool isEmpty() const { return pls.empty(); }
+    void addLight(const VPL& v) { pls.push_back(v); }
+    void normalizeIntensity(int n_paths) {  // :46-66
+        const float inv = 1.0f / n_paths;
+        uint32_t old_id = pls[0].path_id, new_id = 0;
+        for (VPL& p : pls) {
+            if (old_id == p.path_id) p.path_id = new_id;
+            else { old_id = p.path_id; p.path_id = ++new_id; }
+            p.intensity = p.intensity * inv;
+        }
+    }
+};
+
+class Scene {
+public:
+    Scene() = default;
+    Scene(const Scene&) = delete;
+    Scene& operator=(const Scene&) = delete;
+    ~Scene() {
+        if (m_fog) gigl_fog_destroy(m_fog);
+        if (m_scene) gigl_scene_destroy(m_scene);
+    }
+    // RT half of Scene::loadObjects (Source/Common/Scene.cpp:136-158) from already loaded arrays
+    void setGeometry(const std::vector<float>& verts, const std::vector<uint32_t>& tris,
+                     const std::vector<PhongMaterial>& materials, int device = 0) {
+        m_tris = tris;
+        m_materials = materials;
+        check(gigl_scene_create(verts.data(), (uint32_t)(verts.size() / 3), tris.data(), (uint32_t)(tris.size() / 4),
+                                10, 1, 30, 2, 0.25f, device, &m_scene));
+        float b[6];
+        check(gigl_scene_bbox(m_scene, b));
+        m_box_min = v3(b[0], b[1], b[2]);
+        m_box_max = v3(b[3], b[4], b[5]);
+        m_device = device;
+    }
+    // Scene::addFog (Scene.cpp:164-192) with an already loaded density volume
+    void addFog(const std::vector<uint8_t>& dens, const int res[3], float maj_ext_k, float abs_k, float sca_k) {
+        vec3 mx = m_box_max;
+        mx.y = std::min(mx.y, MAX_FOG_HEIGHT);
+        m_fog_min = m_box_min;
+        m_fog_max = mx;
+        const float box[6] = {m_fog_min.x, m_fog_min.y, m_fog_min.z, mx.x, mx.y, mx.z};
+        check(gigl_fog_create(dens.data(), res, box, abs_k + sca_k, 8, m_device, &m_fog));
+        m_maj_ext_k = maj_ext_k; m_abs_k = abs_k; m_sca_k = sca_k;
+        m_fog_enabled = true;
+    }
+    void toggleFog() { m_fog_enabled = !m_fog_enabled; }
+    // Scene::trace, Scene.cpp:234-243.  Like the reference it leaves the ray's t_min/t_max as
+    // KdTree::intersect left them (KdTree.hpp:273-274, :310, :337-338): callers read them.
+    bool trace(rt::Ray& ray, bool is_vis_ray = false) const {
+        int hit = 0;
+        gigl_hit h;
+        float n[3], range[2];
+        const float o[3] = {ray.o.x, ray.o.y, ray.o.z}, d[3] = {ray.d.x, ray.d.y, ray.d.z};
+        check(gigl_trace_one(m_scene, o, d, ray.t_min, ray.t_max, is_vis_ray ? 1 : 0, &hit, &h, n, range));
+        ray.t_min = range[0];
+        ray.t_max = range[1];
+        m_last_hit = h;
+        if (hit) {
+            ray.inters.distance = h.t;
+            ray.inters.normal = v3(n[0], n[1], n[2]);
+            ray.inters.material = &m_materials[m_tris[4 * (size_t)h.tri_id + 3]];
+        }
+        return hit != 0;
+    }
+    // Scene::traceFog, Scene.cpp:245-251: the slab test of the fog box (BBox.cpp:81-109).  A few
+    // float operations on one ray: host arithmetic of the caller, not a batch.
+    IntDist traceFog(const rt::Ray& ray) const {
+        const float t_min = ray.t_min, t_max = ray.t_max;
+        IntDist r;
+        if (!m_fog_enabled) return r;
+        const vec3 b[2] = {m_fog_min, m_fog_max};
+        const int sx = ray.inv_d.x >= 0.0f, sy = ray.inv_d.y >= 0.0f, sz = ray.inv_d.z >= 0.0f;
+        float t_entr = (b[1 - sx].x - ray.o.x) * ray.inv_d.x, t_exit = (b[sx].x - ray.o.x) * ray.inv_d.x;
+        const float t_y_min = (b[1 - sy].y - ray.o.y) * ray.inv_d.y, t_y_max = (b[sy].y - ray.o.y) * ray.inv_d.y;
+        if ((t_entr > t_y_max) || (t_y_min > t_exit)) return r;
+        t_entr = t_entr > t_y_min ? t_entr : t_y_min;
+        t_exit = t_exit < t_y_max ? t_exit : t_y_max;
+        const float t_z_min = (b[1 - sz].z - ray.o.z) * ray.inv_d.z, t_z_max = (b[sz].z - ray.o.z) * ray.inv_d.z;
+        if ((t_entr > t_z_max) || (t_z_min > t_exit)) return r;
+        t_entr = t_entr > t_z_min ? t_entr : t_z_min;
+        t_exit = t_exit < t_z_max ? t_exit : t_z_max;
+        if (t_entr < t_max && t_exit > t_min) { r.entr = t_entr; r.exit = t_exit; }
+        return r;
+    }
+    float sampleDensity(vec3 pos) const {  // DensityField::sampleDensity, on the device
+        const float p[3] = {pos.x, pos.y, pos.z};
+        float out = 0.0f;
+        check(gigl_sample_density(m_fog, p, 1, &out));
+        return out;
+    }
+    float sampleExtK(vec3 pos) const { return (m_abs_k + m_sca_k) * sampleDensity(pos); }  // FogVolume.cpp:32-36
+    float sampleScaK(vec3 pos) const { return m_sca_k * sampleDensity(pos); }              // :38-41
+    float getMajExtK() const { return m_maj_ext_k; }
+    float getScaAlbedo() const { return m_sca_k / (m_abs_k + m_sca_k); }                   // :43-46
+    vec3 boxMin() const { return m_box_min; }
+    vec3 boxMax() const { return m_box_max; }
+    bool fogEnabled() const { return m_fog_enabled; }
+    const gigl_scene* handle() const { return m_scene; }
+    const gigl_hit& lastHit() const { return m_last_hit; }
+
+private:
+    gigl_scene* m_scene = nullptr;
+    gigl_fog* m_fog = nullptr;
+    int m_device = 0;
+    std::vector<uint32_t> m_tris;
+    std::vector<PhongMaterial> m_materials;
+    vec3 m_box_min{}, m_box_max{}, m_fog_min{}, m_fog_max{};
+    float m_maj_ext_k = 0.0f, m_abs_k = 0.0f, m_sca_k = 0.0f;
+    bool m_fog_enabled = false;
+    mutable gigl_hit m_last_hit{};
+};
+
+namespace rt {
+
+struct mat3 { vec3 c0, c1, c2; };
+inline vec3 mul(const mat3& m, vec3 v) {  // Source/Include/GLM/detail/type_mat3x3.inl:593-596
+    return v3(m.c0.x * v.x + m.c1.x * v.y + m.c2.x * v.z, m.c0.y * v.x + m.c1.y * v.y + m.c2.y * v.z,
+              m.c0.z * v.x + m.c1.z * v.y + m.c2.z * v.z);
+}
+inline mat3 spanTangentSpace(vec3 normal) {  // Source/RT/RTBase.h:33-41
+    const vec3 c1 = cross(normal, v3(0.0f, 0.0f, 1.0f)), c2 = cross(normal, v3(0.0f, 1.0f, 0.0f));
+    const vec3 c3 = length(c1) > length(c2) ? c1 : c2;
+    const vec3 tangent = normalize(-c3);
+    return mat3{tangent, cross(normal, tangent), normal};
+}
+inline vec3 genVecSinCos(float phi, float sin_the, float cos_the) {  // RTBase.h:44-50
+    return v3(sin_the * std::cos(phi), sin_the * std::sin(phi), cos_the);
+}
+
+// rt::PhotonTracer::trace, Source/RT/PhotonTracer.cpp:78-188.  `rng` replaces UnitRNG::generate.
+struct PhotonTracer {
+    static void trace(const Scene& scene, vec3 source_pos, vec3 source_intensity, vec3 /*shoot_dir*/,
+                      int max_vpl_count, LightArray& la, const std::function<float()>& rng,
+                      uint32_t* n_paths_out = nullptr) {
+        la.clear();
+        uint32_t n_paths = 0;
+        do {
+            ++n_paths;
+            if (source_pos.z <= MAX_FOG_HEIGHT) (void)rng();              // :86 (result unused, :88-92)
+            const float u1 = rng(), u0 = rng();                           // :90, right-to-left evaluation
+            const float sin_the0 = std::sqrt(1.0f - u1 * u1);
+            const vec3 dir = genVecSinCos(TWO_PI * u0, sin_the0, u1);
+            const float pdf = 0.5f * INV_PI;
+            Ray ray{source_pos, dir};
+            const float ia = 1.0f / pdf;
+            vec3 attenuation = v3(ia, ia, ia);
+            for (int n_bounces = 1; n_bounces <= N_GI_BOUNCES; ++n_bounces) {
+                const bool hit = scene.trace(ray);
+                const IntDist fog_hit = scene.traceFog(ray);
+                if (fog_hit) {
+                    const float f_min = fog_hit.entr > 0.0f ? fog_hit.entr : 0.0f;
+                    const float f_max = fog_hit.exit < ray.inters.distance ? fog_hit.exit : ray.inters.distance;
+                    ray.setValidRange(f_min, f_max);
+                    float t_event = 0.0f;
+                    bool event = false;
+                    const float maj = scene.getMajExtK();
+                    if (0.0f != maj) {                                    // calcEventDistWT, :62-76
+                        float d_event = ray.t_min, p_event = 0.0f;
+                        while (d_event < ray.t_max && p_event < rng()) {
+                            const float dt = -std::log(1.0f - rng()) / maj;
+                            d_event += dt;
+                            p_event = scene.sampleExtK(ray.getPtAtDist(d_event)) / maj;
+                        }
+                        event = d_event < ray.t_max;
+                        t_event = d_event;
+                    }
+                    if (event) {
+                        const vec3 event_pt = ray.getPtAtDist(t_event);
+                        const float sca_k = scene.sampleScaK(event_pt);
+                        if (rng() < scene.getScaAlbedo()) {
+                            const vec3 I = ray.d;
+                            VPL v;
+                            std::memset(&v, 0, sizeof(v));
+                            v.w_pos = event_pt; v.type = 1; v.intensity = source_intensity * attenuation;
+                            v.sca_k = sca_k; v.w_inc = I; v.path_id = n_paths - 1;
+                            la.addLight(v);
+                            if (la.size() == max_vpl_count) break;
+                            const float phi = TWO_PI * rng();             // HGPhaseFunc::importanceSample, :49-58
+                            const float uu = rng();
+                            const float nn = 1.0f - HG_G * HG_G, dd = 1.0f - HG_G + 2.0f * HG_G * uu;
+                            const float q = nn / dd;
+                            const float cos_the = 0.5f / std::fabs(HG_G) * (1.0f + HG_G * HG_G - q * q);
+                            const float sin_the = std::sqrt(1.0f - cos_the * cos_the);
+                            const vec3 O = mul(spanTangentSpace(I), genVecSinCos(phi, sin_the, cos_the));
+                            attenuation = attenuation * 1.0f;
+                            ray = Ray{event_pt, O};
+                            continue;
+                        } else break;
+                    }
+                }
+                if (hit) {
+                    const vec3 hit_pt = ray.getPtAtDist(ray.inters.distance);
+                    const vec3 norm = ray.inters.normal;
+                    if (dot(ray.d, norm) >= 0.0f || hit_pt.z > MAX_FOG_HEIGHT) break;
+                    const PhongMaterial* mat = ray.inters.material;
+                    if (mat->isEmissive()) break;
+                    if (rng() < SURVIVAL_P_RR) {
+                        attenuation = attenuation / SURVIVAL_P_RR;
+                        const vec3 I = -ray.d;
+                        VPL v;
+                        std::memset(&v, 0, sizeof(v));
+                        v.w_pos = hit_pt + 1E-4f * norm; v.type = 2; v.intensity = source_intensity * attenuation;
+                        v.w_inc = I; v.path_id = n_paths - 1; v.w_norm = norm;
+                        v.k_d = mat->k_d; v.k_s = mat->k_s; v.n_s = mat->n_s;
+                        la.addLight(v);
+                        if (la.size() == max_vpl_count) break;
+                        const float bu1 = rng(), bu2 = rng();             // importanceSampleBRDF, RTBase.cpp:70-109
+                        const vec3 lum = v3(0.2126f, 0.7152f, 0.0722f);
+                        const float dw = dot(mat->k_d, lum), gw = dot(mat->k_s, lum);
+                        const float sp_d = dw / (dw + gw);
+                        const float u_rand = rng();
+                        vec3 O, throughput;
+                        if (u_rand < sp_d) {
+                            const float sin_t = std::sqrt(1.0f - bu2);
+                            const vec3 micro = genVecSinCos(TWO_PI * bu1, sin_t, std::sqrt(bu2));
+                            O = mul(spanTangentSpace(norm), micro);
+                            throughput = (mat->k_d * PI) / (micro.z * sp_d);
+                        } else {
+                            const vec3 S = -I + (2.0f * dot(I, norm)) * norm;
+                            const float cos_t = std::pow(bu2, 1.0f / (mat->n_s + 1.0f));
+                            const float sin_t = std::sqrt(1.0f - cos_t * cos_t);
+                            O = mul(spanTangentSpace(S), genVecSinCos(TWO_PI * bu1, sin_t, cos_t));
+                            throughput = (mat->k_s * TWO_PI) / ((mat->n_s + 1.0f) * (1.0f - sp_d));
+                        }
+                        attenuation = attenuation * (throughput * dot(O, norm));
+                        ray = Ray{hit_pt, O, norm};
+                        continue;
+                    } else break;
+                } else break;
+            }
+        } while (la.size() < max_vpl_count && n_paths < (uint32_t)(100 * max_vpl_count));
+        if (n_paths_out) *n_paths_out = n_paths;
+        if (la.size() < max_vpl_count) la.clear();                        // :181-184
+        else la.normalizeIntensity((int)n_paths);
+    }
+};
+
+}  // namespace rt
+}  // namespace gigl_host

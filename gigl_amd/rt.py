@@ -69,7 +69,7 @@ def lib():
         L.gigl_trace_closest.argtypes = [vp, vp, vp, u64, vp]
         L.gigl_trace_any_device.argtypes = [vp, vp, vp, u64, vp, vp]
         L.gigl_trace_any.argtypes = [vp, vp, vp, u64, vp]
-        L.gigl_trace_one.argtypes = [vp, vp, vp, f, f, i, vp, vp, vp]
+        L.gigl_trace_one.argtypes = [vp, vp, vp, f, f, i, vp, vp, vp, vp]
         L.gigl_camera_setup.argtypes = [vp, vp, vp, f, i, i, vp]
         L.gigl_gen_primary_rays_device.argtypes = [vp, vp, i, u64, u64, vp, vp, vp]
         L.gigl_trace_primary_device.argtypes = [vp, vp, i, u64, u64, vp, vp]
@@ -202,8 +202,10 @@ class Scene:
         hit = C.c_int(0)
         rec = np.zeros(1, HIT_DTYPE)
         nrm = np.zeros(3, np.float32)
+        rng = np.zeros(2, np.float32)
         _check(lib().gigl_trace_one(self.h, _p(_f32(o)), _p(_f32(d)), t_min, t_max, int(is_vis_ray),
-                                    C.byref(hit), _p(rec), _p(nrm)))
+                                    C.byref(hit), _p(rec), _p(nrm), _p(rng)))
+        self.last_range = rng
         return bool(hit.value), rec[0], nrm
 
     # ---- device-pointer calls (ints from torch.Tensor.data_ptr()) ----

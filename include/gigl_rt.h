@@ -107,9 +107,12 @@ int gigl_trace_any(const gigl_scene* s, const float* o_tmin, const float* d_tmax
                    uint64_t* occluded_bits);
 /* Single-ray convenience call with Scene::trace semantics (one launch; host pointers).
  * normal_out (optional) receives the normal as Scene::trace leaves it: normalized for
- * closest-hit rays, unnormalized cross(e0,e1) for visibility rays. */
+ * closest-hit rays, unnormalized cross(e0,e1) for visibility rays.  range_out (optional)
+ * receives the ray's (t_min, t_max) as KdTree::intersect leaves them in the caller's Ray
+ * (Source/RT/KdTree.hpp:273-274, :310, :337-338) — PhotonTracer's traceFog call reads them
+ * (Source/RT/PhotonTracer.cpp:96-97, Source/Common/BBox.cpp:104). */
 int gigl_trace_one(const gigl_scene* s, const float o[3], const float d[3], float t_min, float t_max,
-                   int is_vis_ray, int* hit_out, gigl_hit* hit_rec, float normal_out[3]);
+                   int is_vis_ray, int* hit_out, gigl_hit* hit_rec, float normal_out[3], float range_out[2]);
 
 /* PerspectiveCamera (Source/Common/Camera.cpp:15-33): cam = pos, bottom_left, step_x, step_y. */
 int gigl_camera_setup(const float pos[3], const float dir[3], const float up[3], float h_fov,
