@@ -119,6 +119,7 @@ struct TraceParams {
     unsigned long long* bits;
     unsigned long long* stats;   // STATS build only: 8 counters
     float2* ranges;              // optional: the ray's (t_min, t_max) as KdTree::intersect leaves them
+    const unsigned* perm;        // optional (GEN 0): work item i traces ray perm[i] (ray regrouping)
 };
 
 // getPrimaryRay(x + 0.5, y + 0.5), Camera.cpp:65-68; normalize = v * (1/sqrt(dot)) (GLM).
@@ -325,7 +326,8 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
                 if (!have_ray) {
                     const unsigned rank = __popcll(idle & ((1ull << lane) - 1ull));
                     if (rank < take) {
-                        const unsigned idx = pool_next + rank;
+                        unsigned idx = pool_next + rank;
+                        if (GEN == 0 && P.perm) idx = P.perm[idx];
                         ray_idx = idx;
                         best_t = FLT_MAX; best_u = 0.0f; best_v = 0.0f; best_id = kMiss;
                         bool go = fetch_ray<GEN>(P, idx, r);
@@ -455,6 +457,96 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
         atomicAdd(P.stats + 5, (unsigned long long)st_refills);
         atomicAdd(P.stats + 6, (unsigned long long)st_refill_lanes);
         atomicAdd(P.stats + 7, (unsigned long long)st_rays_lanes);
+    }
+}
+
+// ---- ray regrouping: coarse counting sort by (direction octant, Morton cell of the origin) -----
+// Incoherent batches are traced through a permutation that puts rays which start in the same cell
+// of the tree box and head into the same octant next to each other, so the lanes of a wave touch
+// the same cache lines near the top of the tree and in the first leaves.  Results are written by
+// original ray index; the order inside a bin (decided by atomics) never reaches the output.
+constexpr unsigned kBinsPerBlock = 8192;
+
+__device__ __forceinline__ unsigned spread3(unsigned v) {  // 0b...cba -> 0b..c00b00a
+    v &= 0x3FFu;
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+__global__ void __launch_bounds__(256) ray_key_kernel(const float4* __restrict__ o_tmin,
+                                                      const float4* __restrict__ d_tmax, unsigned n, BoxF box,
+                                                      int bits, unsigned* __restrict__ keys,
+                                                      unsigned* __restrict__ hist) {
+    const float cells = (float)(1u << bits);
+    const float sx = cells / (box.mxx - box.mnx), sy = cells / (box.mxy - box.mny), sz = cells / (box.mxz - box.mnz);
+    const float top = cells - 1.0f;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const float4 o = o_tmin[i], d = d_tmax[i];
+        // fminf/fmaxf drop NaNs, so any input lands in a valid cell
+        const unsigned qx = (unsigned)fminf(fmaxf((o.x - box.mnx) * sx, 0.0f), top);
+        const unsigned qy = (unsigned)fminf(fmaxf((o.y - box.mny) * sy, 0.0f), top);
+        const unsigned qz = (unsigned)fminf(fmaxf((o.z - box.mnz) * sz, 0.0f), top);
+        const unsigned oct = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
+        const unsigned key = (oct << (3 * bits)) | spread3(qx) | (spread3(qy) << 1) | (spread3(qz) << 2);
+        keys[i] = key;
+        atomicAdd(&hist[key], 1u);
+    }
+}
+
+__device__ __forceinline__ unsigned block_exclusive_scan_256(unsigned v, unsigned* lds /*[256]*/, unsigned& total) {
+    const unsigned t = threadIdx.x;
+    lds[t] = v;
+    __syncthreads();
+    for (unsigned off = 1; off < 256; off <<= 1) {
+        const unsigned add = t >= off ? lds[t - off] : 0u;
+        __syncthreads();
+        lds[t] += add;
+        __syncthreads();
+    }
+    total = lds[255];
+    return lds[t] - v;
+}
+
+__global__ void __launch_bounds__(256) bin_block_sums_kernel(const unsigned* __restrict__ hist,
+                                                             unsigned* __restrict__ block_sums) {
+    __shared__ unsigned lds[256];
+    const unsigned* h = hist + (size_t)blockIdx.x * kBinsPerBlock;
+    unsigned sum = 0;
+    for (unsigned k = threadIdx.x; k < kBinsPerBlock; k += 256u) sum += h[k];
+    unsigned total;
+    (void)block_exclusive_scan_256(sum, lds, total);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+// in: counts, out: exclusive start offsets (used as scatter cursors)
+__global__ void __launch_bounds__(256) bin_scan_kernel(unsigned* __restrict__ hist,
+                                                       const unsigned* __restrict__ block_sums) {
+    __shared__ unsigned lds[256];
+    unsigned before = 0;
+    for (unsigned k = threadIdx.x; k < blockIdx.x; k += 256u) before += block_sums[k];
+    unsigned base;
+    (void)block_exclusive_scan_256(before, lds, base);
+    __syncthreads();
+    unsigned* h = hist + (size_t)blockIdx.x * kBinsPerBlock;
+    constexpr unsigned per = kBinsPerBlock / 256;
+    unsigned loc[per];
+    unsigned sum = 0;
+#pragma unroll
+    for (unsigned k = 0; k < per; ++k) { loc[k] = h[threadIdx.x * per + k]; sum += loc[k]; }
+    unsigned total;
+    unsigned run = base + block_exclusive_scan_256(sum, lds, total);
+#pragma unroll
+    for (unsigned k = 0; k < per; ++k) { h[threadIdx.x * per + k] = run; run += loc[k]; }
+}
+
+__global__ void __launch_bounds__(256) ray_scatter_kernel(const unsigned* __restrict__ keys, unsigned n,
+                                                          unsigned* __restrict__ cursor, unsigned* __restrict__ perm) {
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const unsigned pos = atomicAdd(&cursor[keys[i]], 1u);
+        perm[pos] = i;
     }
 }
 
@@ -593,6 +685,10 @@ struct Options {
     int chunk = 256;          // rays per work-counter atomic
     int t_exit = 16;          // see trace_kernel: T-phase exit threshold (1..64)
     int stats = 0;            // 1: closest-hit launches run the instrumented build and keep 8 counters
+    int sort_rays = 0;        // explicit-ray batches: 1 regroup rays before tracing, 0 never, -1 deep tree + large
+                              // batch.  Off by default: on MI355X the two atomic passes (2.9 ms per 2^24 rays)
+                              // cost more than the 1.7 ms the regrouped traversal saves
+    int sort_bits = 6;        // cells per axis = 2^sort_bits (4..6)
 };
 Options g_opt;
 std::mutex g_opt_mu;
@@ -637,6 +733,12 @@ struct DeviceGuard {
         if (prev >= 0) (void)hipSetDevice(prev);
     }
 };
+
+unsigned stream_grid(const gigl_scene* s, uint64_t n) {
+    uint64_t g = (n + 255) / 256;
+    const uint64_t cap = (uint64_t)(s ? s->n_cus : 256) * 8;
+    return (unsigned)(g < cap ? (g ? g : 1) : cap);
+}
 
 template <bool ANY, int GEN, int STACK_N>
 int launch_trace_t(const gigl_scene* s, TraceParams& P, const Options& opt, hipStream_t st) {
@@ -689,27 +791,63 @@ int launch_trace(const gigl_scene* s, TraceParams& P, hipStream_t st) {
     P.tris = s->d_tris;
     P.box = s->box;
     P.any_atomic = ANY ? (opt.any_atomic < 0 ? (s->tree.actual_depth > 20 ? 1 : 0) : opt.any_atomic) : 0;
+    // ---- ray regrouping for explicit-ray batches (see ray_key_kernel) ----
+    void* sort_ws = nullptr;
+    P.perm = nullptr;
+    if (GEN == 0 && (opt.sort_rays == 1 || (opt.sort_rays < 0 && s->tree.actual_depth > 20 && P.n >= (1u << 18)))) {
+        const int bits = opt.sort_bits;
+        const unsigned n_bins = 8u << (3 * bits);
+        const unsigned n_blocks = n_bins / kBinsPerBlock;
+        const size_t off_perm = ((size_t)P.n * 4 + 255) & ~(size_t)255;
+        const size_t off_hist = 2 * off_perm;
+        const size_t off_sums = off_hist + (size_t)n_bins * 4;
+        const size_t total = off_sums + (size_t)n_blocks * 4 + 256;
+        if (hipMallocAsync(&sort_ws, total, st) != hipSuccess) return fail(GIGL_ERR_HIP, "hipMallocAsync(regroup)");
+        unsigned* keys = (unsigned*)sort_ws;
+        unsigned* perm = (unsigned*)((char*)sort_ws + off_perm);
+        unsigned* hist = (unsigned*)((char*)sort_ws + off_hist);
+        unsigned* sums = (unsigned*)((char*)sort_ws + off_sums);
+        hipError_t e = hipMemsetAsync(hist, 0, (size_t)n_bins * 4, st);
+        if (e == hipSuccess) {
+            const unsigned g = stream_grid(s, P.n);
+            hipLaunchKernelGGL(ray_key_kernel, dim3(g), dim3(256), 0, st, P.o_tmin, P.d_tmax, P.n, s->box, bits, keys,
+                               hist);
+            hipLaunchKernelGGL(bin_block_sums_kernel, dim3(n_blocks), dim3(256), 0, st, hist, sums);
+            hipLaunchKernelGGL(bin_scan_kernel, dim3(n_blocks), dim3(256), 0, st, hist, sums);
+            hipLaunchKernelGGL(ray_scatter_kernel, dim3(g), dim3(256), 0, st, keys, P.n, hist, perm);
+            e = hipGetLastError();
+        }
+        if (e != hipSuccess) {
+            (void)hipFreeAsync(sort_ws, st);
+            return fail(GIGL_ERR_HIP, std::string("ray regrouping: ") + hipGetErrorString(e));
+        }
+        P.perm = perm;
+        if (ANY) P.any_atomic = 1;  // bits of regrouped rays are not consecutive: OR them in
+    }
     P.refill_thresh = (ANY && !P.any_atomic) ? 64 : opt.refill_thresh;
     if (P.refill_thresh < 1) P.refill_thresh = 1;
     if (P.refill_thresh > 64) P.refill_thresh = 64;
     P.chunk = (unsigned)opt.chunk;
     P.t_exit = opt.t_exit;
+    int rc = GIGL_OK;
     if (ANY && P.any_atomic)
         if (hipMemsetAsync(P.bits, 0, ((size_t)P.n + 63) / 64 * 8, st) != hipSuccess)
-            return fail(GIGL_ERR_HIP, "hipMemsetAsync(bits)");
+            rc = fail(GIGL_ERR_HIP, "hipMemsetAsync(bits)");
     // smallest LDS stack that holds the deepest possible stack avoids the spill path entirely
     int sn = opt.stack_lds;
     const int deepest = s->tree.actual_depth - 1;
     if (deepest <= 8) sn = 8;
     else if (deepest <= 12 && sn >= 12) sn = 12;
     else if (deepest <= 16 && sn >= 16) sn = 16;
-    switch (sn) {
-        case 8: return launch_trace_t<ANY, GEN, 8>(s, P, opt, st);
-        case 12: return launch_trace_t<ANY, GEN, 12>(s, P, opt, st);
-        case 16: return launch_trace_t<ANY, GEN, 16>(s, P, opt, st);
-        case 32: return launch_trace_t<ANY, GEN, 32>(s, P, opt, st);
-        default: return fail(GIGL_ERR_INVALID, "option stack_lds must be 8, 12, 16 or 32");
+    if (rc == GIGL_OK) switch (sn) {
+        case 8: rc = launch_trace_t<ANY, GEN, 8>(s, P, opt, st); break;
+        case 12: rc = launch_trace_t<ANY, GEN, 12>(s, P, opt, st); break;
+        case 16: rc = launch_trace_t<ANY, GEN, 16>(s, P, opt, st); break;
+        case 32: rc = launch_trace_t<ANY, GEN, 32>(s, P, opt, st); break;
+        default: rc = fail(GIGL_ERR_INVALID, "option stack_lds must be 8, 12, 16 or 32");
     }
+    if (sort_ws && hipFreeAsync(sort_ws, st) != hipSuccess && rc == GIGL_OK) rc = fail(GIGL_ERR_HIP, "hipFreeAsync");
+    return rc;
 }
 
 int check_batch(const gigl_scene* s, const void* a, const void* b, uint64_t n, const void* out) {
@@ -721,11 +859,6 @@ int check_batch(const gigl_scene* s, const void* a, const void* b, uint64_t n, c
     return GIGL_OK;
 }
 
-unsigned stream_grid(const gigl_scene* s, uint64_t n) {
-    uint64_t g = (n + 255) / 256;
-    const uint64_t cap = (uint64_t)(s ? s->n_cus : 256) * 8;
-    return (unsigned)(g < cap ? (g ? g : 1) : cap);
-}
 
 }  // namespace
 
@@ -766,6 +899,12 @@ int gigl_set_option(const char* name, int value) {
     } else if (k == "any_atomic") {
         if (value < -1 || value > 1) return fail(GIGL_ERR_INVALID, "any_atomic must be -1, 0 or 1");
         g_opt.any_atomic = value;
+    } else if (k == "sort_rays") {
+        if (value < -1 || value > 1) return fail(GIGL_ERR_INVALID, "sort_rays must be -1, 0 or 1");
+        g_opt.sort_rays = value;
+    } else if (k == "sort_bits") {
+        if (value < 4 || value > 6) return fail(GIGL_ERR_INVALID, "sort_bits must be in 4..6");
+        g_opt.sort_bits = value;
     } else if (k == "stats") {
         g_opt.stats = value ? 1 : 0;
     } else if (k == "t_exit") {

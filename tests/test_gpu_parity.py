@@ -111,16 +111,21 @@ def test_incoherent_bounce_rays_s16(s16):
     assert np.array_equal(occ.astype(bool), want["tri_id"] != rt.GIGL_MISS)
 
 
-@pytest.mark.parametrize("stack_lds,refill,any_atomic", [(8, 1, 1), (8, 64, 0), (12, 16, 1), (16, 32, 0), (32, 8, 1)])
-def test_launch_options_do_not_change_results(s16, stack_lds, refill, any_atomic):
-    """LDS stack depth (8 forces the global spill path: tree depth 31), refill threshold and the
-    any-hit output mode are scheduling choices only."""
+@pytest.mark.parametrize("stack_lds,refill,any_atomic,t_exit,sort_rays,sort_bits",
+                         [(8, 1, 1, 1, 0, 6), (8, 64, 0, 64, 0, 6), (12, 16, 1, 16, 1, 4), (16, 32, 0, 8, 1, 5),
+                          (32, 8, 1, 32, 1, 6), (12, 32, -1, 16, -1, 6)])
+def test_launch_options_do_not_change_results(s16, stack_lds, refill, any_atomic, t_exit, sort_rays, sort_bits):
+    """LDS stack depth (8 forces the global spill path: tree depth 31), refill threshold, T-phase exit
+    threshold, the any-hit output mode and ray regrouping are scheduling choices only."""
     ro, rd = synth.bounce_rays(s16["V"], s16["T"], 50_001, 0xABCD01)
     want = s16["ora"].trace_closest(ro, rd, n_threads=4)
     try:
         rt.set_option("stack_lds", stack_lds)
         rt.set_option("refill_thresh", refill)
         rt.set_option("any_atomic", any_atomic)
+        rt.set_option("t_exit", t_exit)
+        rt.set_option("sort_rays", sort_rays)
+        rt.set_option("sort_bits", sort_bits)
         assert_hits_equal(s16["gpu"].trace(ro, rd), want)
         occ = s16["gpu"].trace(ro, rd, is_vis_ray=True)
         assert np.array_equal(occ.astype(bool), want["tri_id"] != rt.GIGL_MISS)
@@ -128,6 +133,9 @@ def test_launch_options_do_not_change_results(s16, stack_lds, refill, any_atomic
         rt.set_option("stack_lds", 12)
         rt.set_option("refill_thresh", 32)
         rt.set_option("any_atomic", -1)
+        rt.set_option("t_exit", 16)
+        rt.set_option("sort_rays", 0)
+        rt.set_option("sort_bits", 6)
 
 
 def test_edge_cases(gpu_cornell, oracle_cornell):
