@@ -21,6 +21,16 @@
 // the rare deeper entries in a global spill area.
 #include <hip/hip_runtime.h>
 
+// A/B switches kept from tuning (tools/sweep.py over builds, same device, interleaved): the
+// branch-free child-order predicate is worth 1-3 %; the branch-free triangle test costs 10 VGPRs,
+// drops the kernel from 6 to 5 waves/SIMD and loses 4-10 % on coherent batches.
+#ifndef GIGL_BRANCHLESS_TRI
+#define GIGL_BRANCHLESS_TRI 0
+#endif
+#ifndef GIGL_BRANCHLESS_STEP
+#define GIGL_BRANCHLESS_STEP 1
+#endif
+
 #include <cfloat>
 #include <chrono>
 #include <cmath>
@@ -38,7 +48,6 @@ namespace {
 // ------------------------------------------------------------------------------------------
 // device helpers
 // ------------------------------------------------------------------------------------------
-constexpr float kEPS = 1.1920928955078125e-07f;  // std::numeric_limits<float>::epsilon(), RTBase.h:12
 constexpr float kRayOffset = 1E-4f;              // Source/Common/Constants.h:24
 constexpr float kTriEps = 1E-4f;                 // Constants.h:25
 constexpr unsigned kMiss = 0xFFFFFFFFu;
@@ -47,13 +56,17 @@ __device__ __forceinline__ float gmin(float x, float y) { return x < y ? x : y; 
 __device__ __forceinline__ float gmax(float x, float y) { return x > y ? x : y; }
 __device__ __forceinline__ float sel3(unsigned a, float x, float y, float z) { return a == 0u ? x : (a == 1u ? y : z); }
 
-// RTBase.h:18-29.  frexp's exponent comes from v_frexp_exp_i32_f32 (0 for 0/inf/nan, as glibc);
-// `1 << exp` is evaluated with the count masked to 5 bits, as x86 shl does for the reference.
+// RTBase.h:18-29: frexp(t,&e); ++e; e >= 0 ? EPS * (1 << e) : EPS / (1 << -e), with `1 << n` evaluated
+// as x86 shl does for the reference (count masked to 5 bits, 1 << 31 = INT_MIN).  frexp's exponent
+// comes from v_frexp_exp_i32_f32 (0 for 0/inf/nan, as glibc).  Every operand is a power of two, so
+// product and quotient are exact and the result is assembled directly: 2^(k-23) or 2^(-23-k),
+// negative when k == 31.  (tests/test_gpu_parity.py::test_rescaled_eps_device checks 8k values
+// against the oracle's literal evaluation.)
 __device__ __forceinline__ float rescaled_eps(float t) {
-    int e = __builtin_amdgcn_frexp_expf(t);
-    ++e;
-    if (e >= 0) return kEPS * (float)(int)(1u << ((unsigned)e & 31u));
-    return kEPS / (float)(int)(1u << ((unsigned)(-e) & 31u));
+    const int e = __builtin_amdgcn_frexp_expf(t) + 1;
+    const unsigned k = (unsigned)(e >= 0 ? e : -e) & 31u;
+    const unsigned ex = e >= 0 ? 104u + k : 104u - k;   // biased exponent of 2^(-23 +/- k)
+    return __uint_as_float((ex << 23) | (k == 31u ? 0x80000000u : 0u));
 }
 
 struct RayReg {
@@ -207,6 +220,21 @@ __device__ __forceinline__ bool tri_test(const TriRec& T, unsigned id, const Ray
                 e1y = T.b.w, e1z = T.e1z;
     const float pvx = r.dy * e1z - e1y * r.dz, pvy = r.dz * e1x - e1z * r.dx, pvz = r.dx * e1y - e1x * r.dy;
     const float det = (e0x * pvx + e0y * pvy) + e0z * pvz;
+#if GIGL_BRANCHLESS_TRI
+    // The reference nests these tests (det != 0, then u/v, then the distance window); none of them
+    // has a side effect, so evaluating all of them and AND-ing the outcomes accepts exactly the
+    // same hits while the wave runs one straight-line block instead of three nested masks.
+    const float inv_det = 1.0f / det;
+    const float tx = r.ox - p0x, ty = r.oy - p0y, tz = r.oz - p0z;
+    const float qx = ty * e0z - e0y * tz, qy = tz * e0x - e0z * tx, qz = tx * e0y - e0x * ty;
+    const float u = ((tx * pvx + ty * pvy) + tz * pvz) * inv_det;
+    const float v = ((r.dx * qx + r.dy * qy) + r.dz * qz) * inv_det;
+    const float dist = ((e1x * qx + e1y * qy) + e1z * qz) * inv_det;
+    const bool ok = (det != 0.0f) & (u >= -kTriEps) & (v >= -kTriEps) & ((u + v) <= 1.0f + 2.0f * kTriEps) &
+                    (r.tmin < dist) & (dist < r.tmax) & (dist < best_t);
+    if (ok) { best_t = dist; best_u = u; best_v = v; best_id = id; }
+    return ok;
+#else
     if (det != 0.0f) {
         const float inv_det = 1.0f / det;
         const float tx = r.ox - p0x, ty = r.oy - p0y, tz = r.oz - p0z;
@@ -222,6 +250,7 @@ __device__ __forceinline__ bool tri_test(const TriRec& T, unsigned id, const Ray
         }
     }
     return false;
+#endif
 }
 
 // Spill-area accesses are opaque to the optimizer on purpose: merged with the LDS path they
@@ -372,17 +401,21 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
                 const float oa = sel3(axis, r.ox, r.oy, r.oz);
                 const float da = sel3(axis, r.dx, r.dy, r.dz);
                 const float ia = sel3(axis, r.ix, r.iy, r.iz);
+#if GIGL_BRANCHLESS_STEP
+                const bool bottom_first = (oa < split) | ((oa == split) & (da <= 0.0f));
+#else
                 const bool bottom_first = (oa < split) || (oa == split && da <= 0.0f);
+#endif
                 const unsigned first = bottom_first ? node + 1u : above;
                 const unsigned second = bottom_first ? above : node + 1u;
                 const float t_split = (split - oa) * ia;
-                const bool only_first = (t_split > r.tmax) || (t_split <= 0.0f);
+                const bool only_first = (t_split > r.tmax) | (t_split <= 0.0f);
                 const bool only_second = t_split < r.tmin;
-                if (!only_first && !only_second) {  // both children: the far one waits on the stack
+                if (!(only_first | only_second)) {  // both children: the far one waits on the stack
                     push(t_split, second);
                     r.tmax = t_split + rescaled_eps(t_split);
                 }
-                node = (!only_first && only_second) ? second : first;
+                node = (!only_first & only_second) ? second : first;
                 nd = P.nodes[node];
                 leaf_i = 0;
             }

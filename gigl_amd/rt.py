@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgigl_rt.so")
+LIB_PATH = os.environ.get("GIGL_RT_LIB") or os.path.join(_HERE, "lib", "libgigl_rt.so")  # override: A/B builds
 _LIB = None
 
 GIGL_MISS = 0xFFFFFFFF
