@@ -51,6 +51,10 @@ namespace {
 constexpr float kRayOffset = 1E-4f;              // Source/Common/Constants.h:24
 constexpr float kTriEps = 1E-4f;                 // Constants.h:25
 constexpr unsigned kMiss = 0xFFFFFFFFu;
+// float4 per flattened triangle record: 4 = one 64-byte line per triangle (a 48-byte record
+// straddles two lines half of the time, and nearly every triangle fetch of an incoherent batch
+// misses L2)
+constexpr unsigned kTriStride = 4;
 
 __device__ __forceinline__ float gmin(float x, float y) { return x < y ? x : y; }
 __device__ __forceinline__ float gmax(float x, float y) { return x > y ? x : y; }
@@ -158,8 +162,8 @@ __device__ __forceinline__ bool shadow_segment(const TraceParams& P, unsigned pa
     const float4 o = P.prim_o[pt], d = P.prim_d[pt];
     const float t = __uint_as_float(h.y);
     s.px = o.x + t * d.x; s.py = o.y + t * d.y; s.pz = o.z + t * d.z;  // getPtAtDist, RTBase.cpp:124-126
-    const float4 a = P.tris[3 * (size_t)h.x], b = P.tris[3 * (size_t)h.x + 1];
-    const float e1z = P.tris[3 * (size_t)h.x + 2].x;
+    const float4 a = P.tris[kTriStride * (size_t)h.x], b = P.tris[kTriStride * (size_t)h.x + 1];
+    const float e1z = P.tris[kTriStride * (size_t)h.x + 2].x;
     const float e0x = a.w, e0y = b.x, e0z = b.y, e1x = b.z, e1y = b.w;
     float nx = e0y * e1z - e1y * e0z, ny = e0z * e1x - e1z * e0x, nz = e0x * e1y - e1x * e0y;
     const float inv = 1.0f / sqrtf(nx * nx + ny * ny + nz * nz);
@@ -206,7 +210,7 @@ struct TriRec { float4 a, b; float e1z; };
 // the compiler sinks the p0 load below the det != 0 test, which makes it two).
 __device__ __forceinline__ TriRec load_tri(const float4* __restrict__ tris, unsigned id) {
     TriRec t;
-    const float4* p = tris + 3 * (size_t)id;
+    const float4* p = tris + kTriStride * (size_t)id;
     t.a = p[0]; t.b = p[1]; t.e1z = p[2].x;
     asm volatile("" : "+v"(t.a.x), "+v"(t.a.y), "+v"(t.a.z), "+v"(t.a.w));
     return t;
@@ -265,7 +269,8 @@ __device__ __forceinline__ uint2 spill_load(const uint2* p) {
 }
 
 // Device node encoding (same topology and numbering as the reference's m_nodes, KdTree.h:22-65):
-//   interior: w0 = split_pos, w1 = above_child << 3 | axis << 1
+//   interior: w0 = split_pos, w1 = slot of the children pair << 3 | axis << 1 (bottom child first;
+//             slots follow flatten_nodes' treelet order, not the reference's depth-first order)
 //   leaf:     w1 bit0 = 1, bits 1-2 = kind
 //             kind 0: empty          kind 1: one prim, w0 = id
 //             kind 2: two prims, w0 = id0, w1 >> 3 = id1 (saves the m_leaf_prim_ids round trip)
@@ -396,7 +401,7 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
             if (STATS) { ++st_t_iters; st_t_lanes += __popcll(m_t); }
             if (is_t) {
                 const unsigned axis = (nd.y >> 1) & 3u;
-                const unsigned above = nd.y >> 3;
+                const unsigned pair = nd.y >> 3;   // slot of the bottom child; the top child is the next slot
                 const float split = __uint_as_float(nd.x);
                 const float oa = sel3(axis, r.ox, r.oy, r.oz);
                 const float da = sel3(axis, r.dx, r.dy, r.dz);
@@ -406,8 +411,8 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
 #else
                 const bool bottom_first = (oa < split) || (oa == split && da <= 0.0f);
 #endif
-                const unsigned first = bottom_first ? node + 1u : above;
-                const unsigned second = bottom_first ? above : node + 1u;
+                const unsigned first = bottom_first ? pair : pair + 1u;
+                const unsigned second = bottom_first ? pair + 1u : pair;
                 const float t_split = (split - oa) * ia;
                 const bool only_first = (t_split > r.tmax) | (t_split <= 0.0f);
                 const bool only_second = t_split < r.tmin;
@@ -722,6 +727,7 @@ struct Options {
                               // batch.  Off by default: on MI355X the two atomic passes (2.9 ms per 2^24 rays)
                               // cost more than the 1.7 ms the regrouped traversal saves
     int sort_bits = 6;        // cells per axis = 2^sort_bits (4..6)
+    int treelet_levels = 3;   // read at gigl_scene_create: levels of child pairs per cache-line treelet (1..5)
 };
 Options g_opt;
 std::mutex g_opt_mu;
@@ -895,6 +901,93 @@ int check_batch(const gigl_scene* s, const void* a, const void* b, uint64_t n, c
 
 }  // namespace
 
+namespace {
+
+// Re-encodes one host node for the device (see trace_kernel): leaves get a kind field and 2-prim
+// leaves carry their ids inline; interior nodes get the index of their children PAIR.
+inline gigl::KdNode device_leaf(const gigl::KdTreeHost& T, const gigl::KdNode& h) {
+    gigl::KdNode nd = h;
+    const uint32_t np = h.w1 >> 1;
+    if (np == 0) { nd.w0 = 0; nd.w1 = 1u; }
+    else if (np == 1) nd.w1 = 1u | (1u << 1);
+    else if (np == 2) {
+        nd.w0 = T.leaf_prim_ids[h.w0];
+        nd.w1 = 1u | (2u << 1) | (T.leaf_prim_ids[h.w0 + 1] << 3);
+    } else nd.w1 = 1u | (3u << 1) | (np << 3);
+    return nd;
+}
+
+// Device node order.  The reference numbers nodes depth-first (bottom child = parent + 1,
+// KdTree.hpp:254-262), which makes every step to a top child a jump to a far cache line.  Here the
+// two children of a node sit side by side (one 16-byte pair; the parent stores the pair index) and
+// pairs are laid out in treelets: a breadth-first walk of `levels` levels of pairs below a treelet
+// root (1 + 2 + 4 = 7 pairs = 112 B for 3 levels) is stored contiguously and never straddles a
+// 128-byte line, so up to three consecutive steps of a ray read one line.  Topology, leaf contents
+// and traversal order are untouched; only addresses change.  Slot 0 is the root, slot 1 padding.
+void flatten_nodes(const gigl::KdTreeHost& T, int levels, std::vector<gigl::KdNode>& out) {
+    out.clear();
+    const std::vector<gigl::KdNode>& H = T.nodes;
+    if (H.empty()) {  // empty scene: a single empty leaf (KdTree.hpp:9-12)
+        out.push_back(gigl::KdNode{0u, 1u});
+        out.push_back(gigl::KdNode{0u, 1u});
+        return;
+    }
+    out.reserve(H.size() + H.size() / 4 + 16);
+    out.resize(2, gigl::KdNode{0u, 1u});
+    const unsigned max_pairs = (1u << levels) - 1u;           // pairs in a full treelet
+    const unsigned line_pairs = 8;                            // 128 B / 16 B
+    struct Item { uint32_t host; uint32_t slot; };            // interior host node, its device slot
+    std::vector<Item> roots, cur, nxt;
+    if (H[0].w1 & 1u) { out[0] = device_leaf(T, H[0]); return; }
+    out[0] = gigl::KdNode{H[0].w0, H[0].w1 & 6u};
+    roots.push_back(Item{0u, 0u});
+    while (!roots.empty()) {
+        const Item r = roots.back();
+        roots.pop_back();
+        // first pass: how many pairs will this treelet hold?
+        unsigned n_pairs = 0;
+        cur.assign(1, r);
+        for (int lv = 0; lv < levels && !cur.empty(); ++lv) {
+            nxt.clear();
+            for (const Item& it : cur) {
+                ++n_pairs;
+                const uint32_t kids[2] = {it.host + 1u, H[it.host].w1 >> 3};
+                for (uint32_t k : kids)
+                    if (!(H[k].w1 & 1u)) nxt.push_back(Item{k, 0u});
+            }
+            cur.swap(nxt);
+        }
+        size_t pos = out.size() / 2;                           // in pairs
+        if (max_pairs <= line_pairs && (pos % line_pairs) + n_pairs > line_pairs)
+            pos = (pos + line_pairs - 1) / line_pairs * line_pairs;
+        out.resize(2 * pos, gigl::KdNode{0u, 1u});
+        // second pass: emit breadth-first
+        cur.assign(1, r);
+        std::vector<Item> frontier;
+        for (int lv = 0; lv < levels && !cur.empty(); ++lv) {
+            nxt.clear();
+            for (const Item& it : cur) {
+                const uint32_t pair = (uint32_t)(out.size() / 2);
+                out[it.slot].w1 = (out[it.slot].w1 & 6u) | ((uint32_t)(2 * pair) << 3);
+                const uint32_t kids[2] = {it.host + 1u, H[it.host].w1 >> 3};
+                for (uint32_t k : kids) {
+                    const uint32_t slot = (uint32_t)out.size();
+                    if (H[k].w1 & 1u) out.push_back(device_leaf(T, H[k]));
+                    else {
+                        out.push_back(gigl::KdNode{H[k].w0, H[k].w1 & 6u});
+                        (lv + 1 < levels ? nxt : frontier).push_back(Item{k, slot});
+                    }
+                }
+            }
+            cur.swap(nxt);
+        }
+        // deeper treelets of this subtree follow it closely (depth-first over treelets)
+        for (size_t i = frontier.size(); i-- > 0;) roots.push_back(frontier[i]);
+    }
+}
+
+}  // namespace
+
 extern "C" {
 
 const char* gigl_last_error(void) { return g_err.c_str(); }
@@ -935,6 +1028,9 @@ int gigl_set_option(const char* name, int value) {
     } else if (k == "sort_rays") {
         if (value < -1 || value > 1) return fail(GIGL_ERR_INVALID, "sort_rays must be -1, 0 or 1");
         g_opt.sort_rays = value;
+    } else if (k == "treelet_levels") {
+        if (value < 1 || value > 5) return fail(GIGL_ERR_INVALID, "treelet_levels must be in 1..5");
+        g_opt.treelet_levels = value;
     } else if (k == "sort_bits") {
         if (value < 4 || value > 6) return fail(GIGL_ERR_INVALID, "sort_bits must be in 4..6");
         g_opt.sort_bits = value;
@@ -969,6 +1065,11 @@ int gigl_scene_create(const float* verts, uint32_t n_verts, const uint32_t* tris
         if (device < 0 || device >= n_dev) return fail(GIGL_ERR_INVALID, "device index out of range");
     }
 
+    int treelet_levels;
+    {
+        std::lock_guard<std::mutex> lk(g_opt_mu);
+        treelet_levels = g_opt.treelet_levels;
+    }
     gigl_scene* s = new gigl_scene();
     s->device = device;
     s->n_tris = n_tris;
@@ -1000,12 +1101,12 @@ int gigl_scene_create(const float* verts, uint32_t n_verts, const uint32_t* tris
     }
 
     // flattened triangle records: p0, e0 = p1 - p0, e1 = p2 - p0 (RTBase.cpp:151-155)
-    std::vector<float> rec((size_t)n_tris * 12, 0.0f);
+    std::vector<float> rec((size_t)n_tris * 4 * kTriStride, 0.0f);
     for (uint32_t i = 0; i < n_tris; ++i) {
         const float* p0 = verts + 3 * (size_t)tris[4 * (size_t)i];
         const float* p1 = verts + 3 * (size_t)tris[4 * (size_t)i + 1];
         const float* p2 = verts + 3 * (size_t)tris[4 * (size_t)i + 2];
-        float* r = &rec[(size_t)i * 12];
+        float* r = &rec[(size_t)i * 4 * kTriStride];
         r[0] = p0[0]; r[1] = p0[1]; r[2] = p0[2];
         r[3] = p1[0] - p0[0]; r[4] = p1[1] - p0[1]; r[5] = p1[2] - p0[2];
         r[6] = p2[0] - p0[0]; r[7] = p2[1] - p0[1]; r[8] = p2[2] - p0[2];
@@ -1024,9 +1125,12 @@ int gigl_scene_create(const float* verts, uint32_t n_verts, const uint32_t* tris
         uint64_t thr = UINT64_MAX;
         (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr);
     }
-    const size_t nb_nodes = std::max<size_t>(s->tree.nodes.size(), 1) * sizeof(uint2);
+    // ---- device node array: same topology, cache-line treelet order (see flatten_nodes) ----
+    std::vector<gigl::KdNode> dn;
+    flatten_nodes(s->tree, treelet_levels, dn);
+    const size_t nb_nodes = std::max<size_t>(dn.size(), 2) * sizeof(uint2);
     const size_t nb_leaf = std::max<size_t>(s->tree.leaf_prim_ids.size(), 1) * 4;
-    const size_t nb_tris = std::max<size_t>(rec.size(), 12) * 4;
+    const size_t nb_tris = std::max<size_t>(rec.size(), 16) * 4;
     auto cleanup = [&]() {
         if (s->d_nodes) (void)hipFree(s->d_nodes);
         if (s->d_leaf_ids) (void)hipFree(s->d_leaf_ids);
@@ -1046,26 +1150,7 @@ int gigl_scene_create(const float* verts, uint32_t n_verts, const uint32_t* tris
     CREATE_TRY(hipMalloc((void**)&s->d_leaf_ids, nb_leaf));
     CREATE_TRY(hipMalloc((void**)&s->d_tris, nb_tris));
     CREATE_TRY(hipMalloc((void**)&s->d_one, 64));
-    if (!s->tree.nodes.empty()) {
-        // re-encode leaves for the device (see trace_kernel): the ids of 2-prim leaves move inline
-        std::vector<gigl::KdNode> dn(s->tree.nodes);
-        for (gigl::KdNode& nd : dn) {
-            if (!(nd.w1 & 1u)) continue;
-            const uint32_t np = nd.w1 >> 1;
-            if (np == 0) nd.w1 = 1u;
-            else if (np == 1) nd.w1 = 1u | (1u << 1);
-            else if (np == 2) {
-                const uint32_t off = nd.w0;
-                nd.w0 = s->tree.leaf_prim_ids[off];
-                nd.w1 = 1u | (2u << 1) | (s->tree.leaf_prim_ids[off + 1] << 3);
-            } else nd.w1 = 1u | (3u << 1) | (np << 3);
-        }
-        CREATE_TRY(hipMemcpy(s->d_nodes, dn.data(), dn.size() * 8, hipMemcpyHostToDevice));
-    } else {
-        // empty scene: a single empty leaf (KdTree.hpp:9-12)
-        const uint2 leaf = make_uint2(0u, 1u);
-        CREATE_TRY(hipMemcpy(s->d_nodes, &leaf, 8, hipMemcpyHostToDevice));
-    }
+    CREATE_TRY(hipMemcpy(s->d_nodes, dn.data(), dn.size() * 8, hipMemcpyHostToDevice));
     if (!s->tree.leaf_prim_ids.empty())
         CREATE_TRY(hipMemcpy(s->d_leaf_ids, s->tree.leaf_prim_ids.data(), s->tree.leaf_prim_ids.size() * 4,
                              hipMemcpyHostToDevice));
@@ -1213,7 +1298,7 @@ int gigl_trace_one(const gigl_scene* s, const float o[3], const float d[3], floa
             const gigl::KdTreeHost& T = s->tree;
             (void)T;
             float rec[12];
-            HIP_TRY(hipMemcpy(rec, s->d_tris + 3 * (size_t)h.tri_id, 48, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(rec, s->d_tris + kTriStride * (size_t)h.tri_id, 48, hipMemcpyDeviceToHost));
             const float e0x = rec[3], e0y = rec[4], e0z = rec[5], e1x = rec[6], e1y = rec[7], e1z = rec[8];
             float nx = e0y * e1z - e1y * e0z, ny = e0z * e1x - e1z * e0x, nz = e0x * e1y - e1x * e0y;
             if (!is_vis_ray) {

@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--tess", type=int, default=158)
     ap.add_argument("--rays-log2", type=int, default=24)
     ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--treelet", type=int, default=0, help="treelet_levels option set before the scene is created")
     ap.add_argument("variants", nargs="+")
     a = ap.parse_args()
     import torch
@@ -43,7 +44,10 @@ def main():
     dev = torch.device("cuda", 0)
     cv, ct, _, _ = S.load_obj(os.path.join(ROOT, "tests", "golden", "cornell_box.obj"))
     V, T = synth.tessellate(cv, ct, a.tess) if a.tess > 1 else (cv, ct)
+    if a.treelet:
+        rt.set_option("treelet_levels", a.treelet)
     scene = rt.Scene(V, T, device=0, **S.KD_PARAMS)
+    print("device bytes", scene.stats().device_bytes, flush=True)
     n = 1 << a.rays_log2
     ro, rd = synth.bounce_rays(V, T, n, synth.RAY_SEED_16M)
     d_o, d_d = torch.from_numpy(ro).to(dev), torch.from_numpy(rd).to(dev)
