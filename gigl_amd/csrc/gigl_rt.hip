@@ -682,6 +682,43 @@ __global__ void __launch_bounds__(256) transm_shadow_kernel(FogParams F, TracePa
     }
 }
 
+// DensityField::computePiDensity's march (Source/Fog/DensityField.cpp:288-321) for one pixel per
+// lane, after the primary closest-hit pass has produced `hits`.  Stores of one z-plane are
+// coalesced across the lanes of a wave (x fastest).
+__global__ void __launch_bounds__(256) pi_density_kernel(FogParams F, Cam12 cam, unsigned res_x, unsigned n_pix,
+                                                         const uint4* __restrict__ hits, float* __restrict__ out) {
+    const BoxF fb = {F.mnx, F.mny, F.mnz, F.mxx, F.mxy, F.mxz};
+    for (unsigned p = blockIdx.x * 256u + threadIdx.x; p < n_pix; p += gridDim.x * 256u) {
+        RayReg r;
+        float dx, dy, dz;
+        primary_ray(cam.c, res_x, p, dx, dy, dz);
+        r.ox = cam.c[0]; r.oy = cam.c[1]; r.oz = cam.c[2];
+        set_dir(r, dx, dy, dz);
+        r.tmin = 0.0f; r.tmax = FLT_MAX;
+        float entr, exit;
+        if (box_intersect(fb, r, entr, exit)) {
+            const float dist = __uint_as_float(hits[p].y);   // FLT_MAX on a miss, as Ray::Intersection starts
+            const float t_min = gmax(entr, 0.0f), t_max = gmin(exit, dist);
+            const int n_intervals = F.rz * 4;
+            const float dt = (t_max - t_min) / (float)n_intervals;
+            const float ivx = F.mxx - F.mnx, ivy = F.mxy - F.mny, ivz = F.mxz - F.mnz;
+            auto dens_at = [&](float t) {
+                const float qx = r.ox + t * r.dx, qy = r.oy + t * r.dy, qz = r.oz + t * r.dz;
+                return fog_filter(F, (qx - F.mnx) / ivx, (qy - F.mny) / ivy, (qz - F.mnz) / ivz);  // computeNormPos
+            };
+            float prev = dens_at(t_min), dens = 0.0f;
+            for (int i = 1; i <= n_intervals; ++i) {
+                const float cur = dens_at(t_min + (float)i * dt);
+                dens += 0.5f * (cur + prev);
+                prev = cur;
+                if (2 == i % 4) out[p + (size_t)(i / 4) * n_pix] = dens * dt;
+            }
+        } else {
+            for (int z = 0; z < F.rz; ++z) out[p + (size_t)z * n_pix] = 0.0f;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) sample_density_kernel(FogParams F, const float* pos, unsigned n, float* out) {
     for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
         // computeNormPos: (pos - min) / dims, BBox.cpp:53-55
@@ -1475,6 +1512,30 @@ static int map_host(int device, const float* in, size_t in_floats, uint64_t n, f
     if (d_out) (void)hipFree(d_out);
     if (e != hipSuccess) return fail(GIGL_ERR_HIP, std::string("device map: ") + hipGetErrorString(e));
     return GIGL_OK;
+}
+
+int gigl_compute_pi_density_device(const gigl_scene* s, const gigl_fog* f, const float cam[12], int res_x,
+                                   int res_y, float* pi_dens, void* stream) {
+    if (!s || !f || !cam || res_x <= 0 || res_y <= 0) return fail(GIGL_ERR_INVALID, "bad argument");
+    if (s->device == GIGL_DEVICE_NONE) return fail(GIGL_ERR_NO_DEVICE, "host-only scene: no device to trace on");
+    if (f->device != s->device) return fail(GIGL_ERR_INVALID, "fog and scene live on different devices");
+    if (!pi_dens) return fail(GIGL_ERR_INVALID, "NULL output");
+    const uint64_t n = (uint64_t)res_x * (uint64_t)res_y;
+    if (n > (1ull << 28)) return fail(GIGL_ERR_TOO_LARGE, "at most 2^28 pixels per call");
+    DeviceGuard g(s->device);
+    hipStream_t st = (hipStream_t)stream;
+    void* hits = nullptr;
+    HIP_TRY(hipMallocAsync(&hits, n * sizeof(gigl_hit), st));
+    int rc = gigl_trace_primary_device(s, cam, res_x, 0, n, (gigl_hit*)hits, stream);
+    if (rc == GIGL_OK) {
+        Cam12 c;
+        memcpy(c.c, cam, sizeof(c.c));
+        hipLaunchKernelGGL(pi_density_kernel, dim3(stream_grid(s, n)), dim3(256), 0, st, f->fp, c, (unsigned)res_x,
+                           (unsigned)n, (const uint4*)hits, pi_dens);
+        if (hipGetLastError() != hipSuccess) rc = fail(GIGL_ERR_HIP, "pi_density_kernel launch failed");
+    }
+    if (hipFreeAsync(hits, st) != hipSuccess && rc == GIGL_OK) rc = fail(GIGL_ERR_HIP, "hipFreeAsync");
+    return rc;
 }
 
 int gigl_sample_density(const gigl_fog* f, const float* pos, uint64_t n, float* dens_out) {

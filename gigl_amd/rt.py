@@ -24,7 +24,7 @@ SYMBOLS = [
     "gigl_trace_any_device", "gigl_trace_any", "gigl_trace_one", "gigl_camera_setup",
     "gigl_gen_primary_rays_device", "gigl_trace_primary_device", "gigl_shadow_batch_device", "gigl_fog_create",
     "gigl_fog_destroy", "gigl_transmittance_device", "gigl_sample_density", "gigl_debug_rescaled_eps",
-    "gigl_set_option", "gigl_debug_last_stats",
+    "gigl_set_option", "gigl_debug_last_stats", "gigl_compute_pi_density_device",
 ]
 
 
@@ -81,6 +81,7 @@ def lib():
         L.gigl_debug_rescaled_eps.argtypes = [i, vp, u64, vp]
         L.gigl_set_option.argtypes = [C.c_char_p, i]
         L.gigl_debug_last_stats.argtypes = [vp]
+        L.gigl_compute_pi_density_device.argtypes = [vp, vp, vp, i, i, vp, vp]
         for s in SYMBOLS:
             if s != "gigl_last_error":
                 getattr(L, s).restype = C.c_int
@@ -220,6 +221,10 @@ class Scene:
 
     def trace_primary_device(self, cam, res_x, first, n, hits_ptr, stream=0):
         _check(lib().gigl_trace_primary_device(self.h, _p(_f32(cam)), res_x, first, n, hits_ptr, stream))
+
+    def compute_pi_density_device(self, fog, cam, res_x, res_y, out_ptr, stream=0):
+        """DensityField::computePiDensity as one GPU batch (Source/Fog/DensityField.cpp:271-327)."""
+        _check(lib().gigl_compute_pi_density_device(self.h, fog.h, _p(_f32(cam)), res_x, res_y, out_ptr, stream))
 
     def shadow_batch_device(self, o_ptr, d_ptr, hits_ptr, n_pts, lights_ptr, n_lights, bits_ptr, fog=None,
                             transm_ptr=None, stream=0):

@@ -146,6 +146,12 @@ int gigl_fog_destroy(gigl_fog* f);
  * seg_p[i] = (p.x,p.y,p.z,unused), seg_d_distsq[i] = (dir.x,dir.y,dir.z,dist_sq). */
 int gigl_transmittance_device(const gigl_fog* f, const void* seg_p, const void* seg_d_distsq, uint64_t n,
                               float* transm, void* stream);
+/* DensityField::computePiDensity (Source/Fog/DensityField.cpp:271-327): for every pixel of the
+ * camera a primary closest-hit ray and a 4*res_z-interval trapezoid march through the density
+ * volume, storing the running integral at every i%4==2.  pi_dens: device float[res_x*res_y*res_z],
+ * index x + y*res_x + z*res_x*res_y — the payload of the reference's pi_df.3dt. */
+int gigl_compute_pi_density_device(const gigl_scene* s, const gigl_fog* f, const float cam[12], int res_x,
+                                   int res_y, float* pi_dens, void* stream);
 /* DensityField::sampleDensity (Source/Fog/DensityField.cpp:177-202) at n host positions
  * float[3*n] -> float[n]; evaluated on the device. */
 int gigl_sample_density(const gigl_fog* f, const float* pos, uint64_t n, float* dens_out);

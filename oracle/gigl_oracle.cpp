@@ -695,6 +695,45 @@ void ora_transmittance(const ora_fog* fog, const float* sp, const float* sd, uin
     }
 }
 
+/* DensityField::computePiDensity, Source/Fog/DensityField.cpp:271-327.  out: res_x*res_y*res_z
+ * floats, index x + y*res_x + z*res_x*res_y.  PARITY UNPINNED against the reference (its 268 MB
+ * pi_df.3dt was never digested); every piece it is made of is pinned. */
+void ora_compute_pi_density(const ora_scene* s, const ora_fog* fog, const float cam[12], int res_x, int res_y,
+                            float* out, int n_threads) {
+    const V3 pos = v3(cam[0], cam[1], cam[2]), bl = v3(cam[3], cam[4], cam[5]);
+    const V3 sx = v3(cam[6], cam[7], cam[8]), sy = v3(cam[9], cam[10], cam[11]);
+    const Box fbox(fog_min(*fog), fog_max(*fog));
+    const int res_z = fog->res[2];
+    const size_t plane = (size_t)res_x * res_y;
+    const int nt = n_threads < 1 ? 1 : n_threads;
+    (void)nt;
+#pragma omp parallel for schedule(dynamic, 8) num_threads(nt) if (nt > 1)
+    for (int y = 0; y < res_y; ++y)
+        for (int x = 0; x < res_x; ++x) {
+            const V3 dir = (bl + (x + 0.5f) * sx) + (y + 0.5f) * sy;      /* Camera.cpp:66 */
+            Ray ray = make_ray(pos, normalize(dir));
+            float entr, exit;
+            if (box_intersect(fbox, ray, entr, exit)) {
+                scene_trace(*s, ray, false);
+                const float t_min = gmax(entr, 0.0f);
+                const float t_max = gmin(exit, ray.dist);
+                const int n_intervals = res_z * 4;
+                const float dt = (t_max - t_min) / n_intervals;
+                float prev_dens = sample_density(*fog, ray.o + t_min * ray.d);
+                float dens = 0.0f;
+                for (int i = 1; i <= n_intervals; ++i) {
+                    const float t = t_min + i * dt;
+                    const float curr_dens = sample_density(*fog, ray.o + t * ray.d);
+                    dens += 0.5f * (curr_dens + prev_dens);
+                    prev_dens = curr_dens;
+                    if (2 == i % 4) out[x + (size_t)y * res_x + (size_t)(i / 4) * plane] = dens * dt;
+                }
+            } else {
+                for (int z = 0; z < res_z; ++z) out[x + (size_t)y * res_x + (size_t)z * plane] = 0.0f;
+            }
+        }
+}
+
 /* glm::simplex(vec3), Source/Include/GLM/gtc/noise.inl:679-751, scalarised */
 static float glm_simplex3(V3 v) {
     const float Cx = (float)(1.0 / 6.0), Cy = (float)(1.0 / 3.0);

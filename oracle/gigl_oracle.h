@@ -105,6 +105,12 @@ float ora_sample_density(const ora_fog* fog, const float pos[3]);
 void ora_transmittance(const ora_fog* fog, const float* seg_p, const float* seg_d_distsq,
                        uint64_t n, float* transm, int n_threads);
 
+/* DensityField::computePiDensity (Source/Fog/DensityField.cpp:271-327): per pixel a primary
+ * closest-hit ray, then a 4*res_z-interval trapezoid march storing the running integral at every
+ * i%4==2.  out: float[res_x*res_y*res_z], x fastest, then y, then z.  PARITY UNPINNED. */
+void ora_compute_pi_density(const ora_scene* s, const ora_fog* fog, const float cam[12], int res_x,
+                            int res_y, float* out, int n_threads);
+
 /* DensityField noise constructor (Source/Fog/DensityField.cpp:18-76) with GLM 0.9.5.4's
  * simplex(vec3) (Source/Include/GLM/gtc/noise.inl:679-751).  out: res^3 bytes. */
 void ora_make_density(const int res[3], float freq, float ampl, uint8_t* out);

@@ -62,6 +62,7 @@ def lib():
         L.ora_sample_density.restype = C.c_float
         L.ora_sample_density.argtypes = [C.c_void_p, C.c_void_p]
         L.ora_transmittance.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
+        L.ora_compute_pi_density.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.ora_make_density.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_void_p]
         L.ora_photon_trace.restype = C.c_int
         L.ora_photon_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_float, C.c_float,
@@ -211,6 +212,12 @@ def transmittance(fog, seg_p, seg_d_distsq, n_threads=1):
     sp, sd = _f32(seg_p).reshape(-1, 4), _f32(seg_d_distsq).reshape(-1, 4)
     out = np.zeros(len(sp), np.float32)
     lib().ora_transmittance(fog.ref(), _p(sp), _p(sd), len(sp), _p(out), n_threads)
+    return out
+
+
+def compute_pi_density(scene, fog, cam, res_x, res_y, n_threads=1):
+    out = np.zeros((fog.dens.shape[0], res_y, res_x), np.float32)
+    lib().ora_compute_pi_density(scene.h, fog.ref(), _p(_f32(cam)), res_x, res_y, _p(out), n_threads)
     return out
 
 

@@ -271,3 +271,68 @@ def test_shadow_batch_cornell(gpu_cornell, oracle_cornell, cornell_cam, density,
     rel = np.abs(got_tr.astype(np.float64) - want_tr) / np.maximum(np.abs(want_tr), 1e-30)
     assert float(rel.max()) <= REL_TOL
     fog_g.close()
+
+
+@pytest.mark.parametrize("res", [(96, 64), (1024, 1024)])
+def test_compute_pi_density(gpu_cornell, oracle_cornell, density, fog_box, res):
+    """SURVEY.md §8(f).1: DensityField::computePiDensity as one GPU batch (primary closest-hit, then
+    a 256-interval march per pixel), against the oracle.  (1024, 1024) is the reference's own
+    configuration: the 268 MB payload of pi_df.3dt.  PARITY UNPINNED against the reference file
+    itself, which was never digested."""
+    torch = pytest.importorskip("torch")
+    rx, ry = res
+    cam = rt.camera_setup(S.CAM_POS, S.CAM_DIR, S.CAM_UP, S.CAM_HFOV, rx, ry)
+    fog_o = O.Fog(density, fog_box, np.float32(S.ABS_K) + np.float32(S.SCA_K))
+    fog_g = rt.FogVolume(density, fog_box, S.ABS_K, S.SCA_K)
+    out = torch.full((64, ry, rx), -1.0, dtype=torch.float32, device="cuda:0")
+    gpu_cornell.compute_pi_density_device(fog_g, cam, rx, ry, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    want = O.compute_pi_density(oracle_cornell, fog_o, cam, rx, ry, n_threads=8)
+    assert (want > 0).mean() > 0.5
+    rel = np.abs(got.astype(np.float64) - want) / np.maximum(np.abs(want.astype(np.float64)), 1e-30)
+    assert float(rel.max()) <= REL_TOL
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "pi density bits differ"
+    # size-independent property: the running integral never decreases along a ray
+    assert (np.diff(got, axis=0) >= 0).all()
+    fog_g.close()
+
+
+def test_full_size_scene_s158(cornell):
+    """configs[2] at its full scene size (998,560 triangles, tree depth 31, 8.4 M nodes): tree equal
+    to the oracle's, 2^21 incoherent rays bit-exact against the oracle, and on the full 2^24-ray batch
+    the size-independent properties: any-hit bits == (closest-hit id != miss), every hit inside its
+    ray's range, and a regrouped (permuted) launch returning the identical buffer."""
+    torch = pytest.importorskip("torch")
+    V, T = synth.tessellate(cornell["verts"], cornell["tris"], 158)
+    assert len(T) == 998560
+    g = rt.Scene(V, T, device=0, **S.KD_PARAMS)
+    o = O.OracleScene(V, T, **S.KD_PARAMS)
+    nodes, leaf = g.export_tree()
+    assert np.array_equal(nodes, o.nodes()) and np.array_equal(leaf, o.leaf_prim_ids())
+    n = 1 << 24
+    ro, rd = synth.bounce_rays(V, T, n, synth.RAY_SEED_16M)
+    d_o, d_d = torch.from_numpy(ro).cuda(), torch.from_numpy(rd).cuda()
+    hits = torch.empty((n, 4), dtype=torch.int32, device="cuda:0")
+    bits = torch.zeros((n + 63) // 64, dtype=torch.int64, device="cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    g.trace_closest_device(d_o.data_ptr(), d_d.data_ptr(), n, hits.data_ptr(), st)
+    g.trace_any_device(d_o.data_ptr(), d_d.data_ptr(), n, bits.data_ptr(), st)
+    torch.cuda.synchronize()
+    got = hits.cpu().numpy().view(rt.HIT_DTYPE).reshape(-1)
+    m = 1 << 21
+    assert_hits_equal(got[:m], o.trace_closest(ro[:m], rd[:m], n_threads=8))
+    hit = got["tri_id"] != rt.GIGL_MISS
+    occ = rt.unpack_bits(bits.cpu().numpy().view(np.uint64), n)
+    assert np.array_equal(occ.astype(bool), hit)
+    assert (got["tri_id"][hit] < len(T)).all() and (got["t"][hit] > 0).all() and np.isfinite(got["t"][hit]).all()
+    assert (got["t"][~hit] == FLT_MAX).all()
+    try:
+        rt.set_option("sort_rays", 1)
+        hits2 = torch.empty_like(hits)
+        g.trace_closest_device(d_o.data_ptr(), d_d.data_ptr(), n, hits2.data_ptr(), st)
+        torch.cuda.synchronize()
+        assert torch.equal(hits, hits2)
+    finally:
+        rt.set_option("sort_rays", 0)
+    g.close()
