@@ -267,6 +267,9 @@ def extras(torch, rt, S, scene, d_o, d_d, n, device):
     ms = timeit(lambda: cs.shadow_batch_device(po.data_ptr(), pd.data_ptr(), ph.data_ptr(), npix, dl.data_ptr(), 150,
                                                None, fog=fog, transm_ptr=tr.data_ptr(), stream=sh), reps=2)
     res["cornell_transmittance_msegments_s"] = round(nhit * 150 / ms / 1e3, 2)
+    pi = torch.empty((64, 1024, 1024), dtype=torch.float32, device=device)
+    ms = timeit(lambda: cs.compute_pi_density_device(fog, cam, 1024, 1024, pi.data_ptr(), sh), reps=2)
+    res["compute_pi_density_1024_ms"] = round(ms, 3)   # reference: 3.1 s on 8 CPU threads
     fog.close()
     cs.close()
     return res

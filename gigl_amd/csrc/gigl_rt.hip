@@ -13,12 +13,15 @@
 // MSVC /fp:precise), correctly rounded f32 divide and sqrt (hipcc default), f32 denormals kept.
 // min/max are written as selects (GLM func_common.inl:377,395), never fminf/fmaxf.
 //
-// Execution model: persistent wavefronts.  Each 64-lane wave pulls ray indices from a global
-// counter, one ray per lane, and refills idle lanes (found with a ballot) once enough of them
-// have retired, so long-tailed rays do not hold 63 idle lanes hostage.  The per-lane traversal
-// stack holds (t_split, node) pairs — t_min/t_max are rebuilt from them on pop, see pop_stack() —
-// with the first STACK_N entries in LDS (lane-interleaved, conflict-free ds_read/write_b64) and
-// the rare deeper entries in a global spill area.
+// Execution model: persistent wavefronts.  Each 64-lane wave takes ray indices from a global
+// counter (one atomic per `chunk` rays), one ray per lane, and refills idle lanes (found with a
+// ballot) once enough of them have retired, so long-tailed rays do not hold 63 idle lanes hostage.
+// Lanes run a two-state machine (Traversing / at a Leaf, see trace_kernel).  The per-lane traversal
+// stack holds (t_split, node) pairs — t_min/t_max are rebuilt from them on pop — with the first
+// STACK_N entries in LDS (lane-interleaved, conflict-free ds_read/write_b64) and the rare deeper
+// entries (0.04 % of pushes on the 1M-triangle scene) in a global spill area.
+// Device data layout: flatten_nodes() (pair-addressed nodes in 128-byte treelets) and the 64-byte
+// triangle records built in gigl_scene_create().
 #include <hip/hip_runtime.h>
 
 // A/B switches kept from tuning (tools/sweep.py over builds, same device, interleaved): the
@@ -109,7 +112,7 @@ __device__ __forceinline__ bool box_intersect(const BoxF& b, const RayReg& r, fl
 struct TraceParams {
     const uint2* nodes;
     const unsigned* leaf_ids;
-    const float4* tris;   // 3 float4 per triangle: (p0.xyz,e0.x) (e0.yz,e1.xy) (e1.z,-,-,-)
+    const float4* tris;   // kTriStride float4 per triangle: (p0.xyz,e0.x) (e0.yz,e1.xy) (e1.z,mat,-,-) (-)
     BoxF box;
     unsigned n;
     unsigned* counter;
@@ -203,7 +206,7 @@ __device__ __forceinline__ bool fetch_ray(const TraceParams& P, unsigned idx, Ra
     }
 }
 
-// Flattened triangle record: 3 float4 = (p0.xyz, e0.x) (e0.yz, e1.xy) (e1.z, mat, -, -).
+// Flattened triangle record, one 64-byte line: (p0.xyz, e0.x) (e0.yz, e1.xy) (e1.z, mat, -, -) (-).
 struct TriRec { float4 a, b; float e1z; };
 
 // All three loads are issued before any use: one memory round trip per triangle (left to itself
@@ -822,8 +825,14 @@ int launch_trace_t(const gigl_scene* s, TraceParams& P, const Options& opt, hipS
     if (!ANY && GEN == 0 && STACK_N == 12 && opt.stats) kern = trace_kernel<ANY, GEN, 12, kBlock, true>;
     int per_cu = opt.blocks_per_cu;
     if (per_cu <= 0) {
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kBlock, 0));
-        if (per_cu < 1) per_cu = 1;
+        static int cached[2] = {0, 0};  // per instantiation; [1] is the instrumented build
+        int& c = cached[(!ANY && GEN == 0 && STACK_N == 12 && opt.stats) ? 1 : 0];
+        if (c <= 0) {
+            int q = 0;
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, kern, kBlock, 0));
+            c = q < 1 ? 1 : q;
+        }
+        per_cu = c;
     }
     unsigned grid = (unsigned)(s->n_cus * per_cu);
     const unsigned need = (P.n + kBlock - 1) / kBlock;
@@ -834,7 +843,10 @@ int launch_trace_t(const gigl_scene* s, TraceParams& P, const Options& opt, hipS
     const size_t ws_bytes = 256 + spill_entries * sizeof(uint2);
     void* ws = nullptr;
     HIP_TRY(hipMallocAsync(&ws, ws_bytes, st));
-    HIP_TRY(hipMemsetAsync(ws, 0, 256, st));
+    if (hipMemsetAsync(ws, 0, 256, st) != hipSuccess) {
+        (void)hipFreeAsync(ws, st);
+        return fail(GIGL_ERR_HIP, "hipMemsetAsync(workspace)");
+    }
     P.counter = (unsigned*)ws;
     P.spill = (uint2*)((char*)ws + 256);
     P.spill_stride = grid * kBlock;
