@@ -54,6 +54,7 @@ namespace {
 constexpr float kRayOffset = 1E-4f;              // Source/Common/Constants.h:24
 constexpr float kTriEps = 1E-4f;                 // Constants.h:25
 constexpr unsigned kMiss = 0xFFFFFFFFu;
+constexpr unsigned kLeafBit = 0x80000000u, kLeafPayload = 0x1FFFFFFFu;   // device node word 1, see trace_kernel
 // float4 per flattened triangle record: 4 = one 64-byte line per triangle (a 48-byte record
 // straddles two lines half of the time, and nearly every triangle fetch of an incoherent batch
 // misses L2)
@@ -69,12 +70,15 @@ __device__ __forceinline__ float sel3(unsigned a, float x, float y, float z) { r
 // product and quotient are exact and the result is assembled directly: 2^(k-23) or 2^(-23-k),
 // negative when k == 31.  (tests/test_gpu_parity.py::test_rescaled_eps_device checks 8k values
 // against the oracle's literal evaluation.)
-__device__ __forceinline__ float rescaled_eps(float t) {
-    const int e = __builtin_amdgcn_frexp_expf(t) + 1;
+__device__ __forceinline__ float eps_from_exp(int e /* frexp exponent + 1 */) {
     const unsigned k = (unsigned)(e >= 0 ? e : -e) & 31u;
     const unsigned ex = e >= 0 ? 104u + k : 104u - k;   // biased exponent of 2^(-23 +/- k)
     return __uint_as_float((ex << 23) | (k == 31u ? 0x80000000u : 0u));
 }
+__device__ __forceinline__ float rescaled_eps(float t) { return eps_from_exp(__builtin_amdgcn_frexp_expf(t) + 1); }
+// trace_kernel keeps the function as a table in LDS, indexed by frexp exponent + kEpsBias: the
+// exponent of a float (denormals included) lies in [-148, 128].
+constexpr int kEpsBias = 148, kEpsTable = 277;
 
 struct RayReg {
     float ox, oy, oz, dx, dy, dz, ix, iy, iz, tmin, tmax;
@@ -272,17 +276,23 @@ __device__ __forceinline__ uint2 spill_load(const uint2* p) {
 }
 
 // Device node encoding (same topology and numbering as the reference's m_nodes, KdTree.h:22-65):
-//   interior: w0 = split_pos, w1 = slot of the children pair << 3 | axis << 1 (bottom child first;
+//   interior: w0 = split_pos, w1 = slot of the children pair << 2 | axis (bottom child first;
 //             slots follow flatten_nodes' treelet order, not the reference's depth-first order)
-//   leaf:     w1 bit0 = 1, bits 1-2 = kind
+//   leaf:     w1 bit 31 = 1 (so "still descending" is one signed compare), bits 29-30 = kind,
+//             bits 0-28 = payload
 //             kind 0: empty          kind 1: one prim, w0 = id
-//             kind 2: two prims, w0 = id0, w1 >> 3 = id1 (saves the m_leaf_prim_ids round trip)
-//             kind 3: n >= 3 prims, w0 = offset into leaf_ids, w1 >> 3 = n
+//             kind 2: two prims, w0 = id0, payload = id1 (saves the m_leaf_prim_ids round trip)
+//             kind 3: n >= 3 prims, w0 = offset into leaf_ids, payload = n
+// A lane without a ray always holds a leaf word, so the T-phase test needs no have_ray term.
 template <bool ANY, int GEN, int STACK_N, int BLOCK, bool STATS = false>
 __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
     __shared__ uint2 s_stack[STACK_N * BLOCK];
+    __shared__ float s_eps[kEpsTable];
     const unsigned tid = threadIdx.x;
     const unsigned lane = tid & 63u;
+    for (int i = (int)tid; i < kEpsTable; i += BLOCK) s_eps[i] = eps_from_exp(i - kEpsBias + 1);
+    __syncthreads();
+    auto eps_of = [&](float t) { return s_eps[(unsigned)(__builtin_amdgcn_frexp_expf(t) + kEpsBias)]; };
     uint2* const my_stack = s_stack + tid;
     uint2* const my_spill = P.spill + ((size_t)blockIdx.x * BLOCK + tid);
 
@@ -328,7 +338,7 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
     // a T-phase (interior steps, repeated while at least t_exit lanes are still descending, so a
     // few stragglers do not stall the lanes already waiting at leaves) and an L-phase (one pair of
     // triangle tests per lane at a leaf).  Per ray the sequence of operations is the reference's.
-    uint2 nd = make_uint2(0u, 1u);
+    uint2 nd = make_uint2(0u, kLeafBit);
     unsigned leaf_i = 0;
     bool need_load = false;
     const int t_exit = P.t_exit;
@@ -373,14 +383,14 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
                             float entr, exit;
                             go = box_intersect(P.box, r, entr, exit);
                             if (go) {
-                                const float nmin = gmax(r.tmin, entr - rescaled_eps(entr));
-                                const float nmax = gmin(r.tmax, exit + rescaled_eps(exit));
+                                const float nmin = gmax(r.tmin, entr - eps_of(entr));
+                                const float nmax = gmin(r.tmax, exit + eps_of(exit));
                                 r.tmin = nmin; r.tmax = nmax;
                                 root_tmax = nmax;
                                 go = !(best_t < r.tmin);  // KdTree.hpp:280
                             }
                         }
-                        if (go) { have_ray = true; node = 0; sp = -1; need_load = true; }
+                        if (go) { have_ray = true; node = 0; sp = -1; need_load = true; leaf_i = 0; }
                         else finish(false);
                     }
                 }
@@ -393,51 +403,51 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
         }
         if (have_ray && need_load) {
             nd = P.nodes[node];
-            leaf_i = 0;
             need_load = false;
         }
         // ---- T-phase: KdTree.hpp:284-311 ----
         for (;;) {
-            const bool is_t = have_ray && !(nd.y & 1u);
+            const bool is_t = (int)nd.y >= 0;
             const unsigned long long m_t = __ballot(is_t);
             if (m_t == 0ull) break;
             if (STATS) { ++st_t_iters; st_t_lanes += __popcll(m_t); }
             if (is_t) {
-                const unsigned axis = (nd.y >> 1) & 3u;
-                const unsigned pair = nd.y >> 3;   // slot of the bottom child; the top child is the next slot
+                const unsigned axis = nd.y & 3u;
+                const unsigned pair = nd.y >> 2;   // slot of the bottom child; the top child is the next slot
                 const float split = __uint_as_float(nd.x);
                 const float oa = sel3(axis, r.ox, r.oy, r.oz);
-                const float da = sel3(axis, r.dx, r.dy, r.dz);
                 const float ia = sel3(axis, r.ix, r.iy, r.iz);
-#if GIGL_BRANCHLESS_STEP
-                const bool bottom_first = (oa < split) | ((oa == split) & (da <= 0.0f));
-#else
-                const bool bottom_first = (oa < split) || (oa == split && da <= 0.0f);
-#endif
-                const unsigned first = bottom_first ? pair : pair + 1u;
-                const unsigned second = bottom_first ? pair + 1u : pair;
+                // KdTree.hpp:289-291: below the plane, or on it and not heading up.  The direction
+                // only matters for an origin exactly on the plane, so it is selected on that
+                // (wave-uniform, rarely taken) branch only.
+                bool bottom_first = oa < split;
+                if (__ballot(oa == split) != 0ull) {
+                    asm volatile("" ::: "memory");  // keeps this a real branch (else it is if-converted)
+                    bottom_first = bottom_first | ((oa == split) & (sel3(axis, r.dx, r.dy, r.dz) <= 0.0f));
+                }
                 const float t_split = (split - oa) * ia;
                 const bool only_first = (t_split > r.tmax) | (t_split <= 0.0f);
                 const bool only_second = t_split < r.tmin;
+                const bool take_second = !only_first & only_second;
+                // first = bottom_first ? pair : pair + 1, second = the other slot
                 if (!(only_first | only_second)) {  // both children: the far one waits on the stack
-                    push(t_split, second);
-                    r.tmax = t_split + rescaled_eps(t_split);
+                    push(t_split, pair + (bottom_first ? 1u : 0u));
+                    r.tmax = t_split + eps_of(t_split);
                 }
-                node = (!only_first & only_second) ? second : first;
+                node = pair + (bottom_first == take_second ? 1u : 0u);
                 nd = P.nodes[node];
-                leaf_i = 0;
             }
             if ((int)__popcll(m_t) < t_exit) break;
         }
         // ---- L-phase: KdTree.hpp:312-343.  Prims are tested in m_leaf_prim_ids order, two per
         // round; both triangles' loads are issued before the first test. ----
         if (STATS) {
-            const unsigned long long m_l = __ballot(have_ray && (nd.y & 1u));
+            const unsigned long long m_l = __ballot(have_ray && (int)nd.y < 0);
             if (m_l) { ++st_l_rounds; st_l_lanes += __popcll(m_l); }
         }
-        if (have_ray && (nd.y & 1u)) {
-            const unsigned kind = (nd.y >> 1) & 3u;
-            const unsigned n_prims = kind == 3u ? (nd.y >> 3) : kind;
+        if (have_ray && (int)nd.y < 0) {
+            const unsigned kind = (nd.y >> 29) & 3u;
+            const unsigned n_prims = kind == 3u ? (nd.y & kLeafPayload) : kind;
             bool any_done = false;
             if (leaf_i < n_prims) {
                 unsigned id0, id1;
@@ -447,7 +457,7 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
                     id1 = two ? P.leaf_ids[nd.x + leaf_i + 1] : id0;
                 } else {
                     id0 = nd.x;
-                    id1 = two ? (nd.y >> 3) : id0;
+                    id1 = two ? (nd.y & kLeafPayload) : id0;
                 }
                 const TriRec t0 = load_tri(P.tris, id0);
                 const TriRec t1 = load_tri(P.tris, id1);
@@ -469,16 +479,16 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
                     const uint2 e = peek(sp);
                     const float ts = __uint_as_float(e.x);
                     node = e.y;
-                    r.tmin = ts - rescaled_eps(ts);
+                    r.tmin = ts - eps_of(ts);
                     if (sp > 0) {
                         const float tb = __uint_as_float(peek(sp - 1).x);
-                        r.tmax = tb + rescaled_eps(tb);
+                        r.tmax = tb + eps_of(tb);
                     } else {
                         r.tmax = root_tmax;
                     }
                     --sp;
                     if (best_t < r.tmin) finish(false);  // KdTree.hpp:280
-                    else need_load = true;
+                    else { need_load = true; leaf_i = 0; }
                 } else {
                     finish(false);
                 }
@@ -835,6 +845,7 @@ int launch_trace_t(const gigl_scene* s, TraceParams& P, const Options& opt, hipS
         per_cu = c;
     }
     unsigned grid = (unsigned)(s->n_cus * per_cu);
+    if (getenv("GIGL_RT_DEBUG")) fprintf(stderr, "[gigl_rt] trace launch: %d blocks/CU x %d CUs\n", per_cu, s->n_cus);
     const unsigned need = (P.n + kBlock - 1) / kBlock;
     if (grid > need) grid = need;
     if (grid == 0) return GIGL_OK;
@@ -957,12 +968,12 @@ namespace {
 inline gigl::KdNode device_leaf(const gigl::KdTreeHost& T, const gigl::KdNode& h) {
     gigl::KdNode nd = h;
     const uint32_t np = h.w1 >> 1;
-    if (np == 0) { nd.w0 = 0; nd.w1 = 1u; }
-    else if (np == 1) nd.w1 = 1u | (1u << 1);
+    if (np == 0) { nd.w0 = 0; nd.w1 = kLeafBit; }
+    else if (np == 1) nd.w1 = kLeafBit | (1u << 29);
     else if (np == 2) {
         nd.w0 = T.leaf_prim_ids[h.w0];
-        nd.w1 = 1u | (2u << 1) | (T.leaf_prim_ids[h.w0 + 1] << 3);
-    } else nd.w1 = 1u | (3u << 1) | (np << 3);
+        nd.w1 = kLeafBit | (2u << 29) | T.leaf_prim_ids[h.w0 + 1];
+    } else nd.w1 = kLeafBit | (3u << 29) | np;
     return nd;
 }
 
@@ -977,18 +988,18 @@ void flatten_nodes(const gigl::KdTreeHost& T, int levels, std::vector<gigl::KdNo
     out.clear();
     const std::vector<gigl::KdNode>& H = T.nodes;
     if (H.empty()) {  // empty scene: a single empty leaf (KdTree.hpp:9-12)
-        out.push_back(gigl::KdNode{0u, 1u});
-        out.push_back(gigl::KdNode{0u, 1u});
+        out.push_back(gigl::KdNode{0u, kLeafBit});
+        out.push_back(gigl::KdNode{0u, kLeafBit});
         return;
     }
     out.reserve(H.size() + H.size() / 4 + 16);
-    out.resize(2, gigl::KdNode{0u, 1u});
+    out.resize(2, gigl::KdNode{0u, kLeafBit});
     const unsigned max_pairs = (1u << levels) - 1u;           // pairs in a full treelet
     const unsigned line_pairs = 8;                            // 128 B / 16 B
     struct Item { uint32_t host; uint32_t slot; };            // interior host node, its device slot
     std::vector<Item> roots, cur, nxt;
     if (H[0].w1 & 1u) { out[0] = device_leaf(T, H[0]); return; }
-    out[0] = gigl::KdNode{H[0].w0, H[0].w1 & 6u};
+    out[0] = gigl::KdNode{H[0].w0, (H[0].w1 >> 1) & 3u};
     roots.push_back(Item{0u, 0u});
     while (!roots.empty()) {
         const Item r = roots.back();
@@ -1009,7 +1020,7 @@ void flatten_nodes(const gigl::KdTreeHost& T, int levels, std::vector<gigl::KdNo
         size_t pos = out.size() / 2;                           // in pairs
         if (max_pairs <= line_pairs && (pos % line_pairs) + n_pairs > line_pairs)
             pos = (pos + line_pairs - 1) / line_pairs * line_pairs;
-        out.resize(2 * pos, gigl::KdNode{0u, 1u});
+        out.resize(2 * pos, gigl::KdNode{0u, kLeafBit});
         // second pass: emit breadth-first
         cur.assign(1, r);
         std::vector<Item> frontier;
@@ -1017,13 +1028,13 @@ void flatten_nodes(const gigl::KdTreeHost& T, int levels, std::vector<gigl::KdNo
             nxt.clear();
             for (const Item& it : cur) {
                 const uint32_t pair = (uint32_t)(out.size() / 2);
-                out[it.slot].w1 = (out[it.slot].w1 & 6u) | ((uint32_t)(2 * pair) << 3);
+                out[it.slot].w1 = (out[it.slot].w1 & 3u) | ((uint32_t)(2 * pair) << 2);
                 const uint32_t kids[2] = {it.host + 1u, H[it.host].w1 >> 3};
                 for (uint32_t k : kids) {
                     const uint32_t slot = (uint32_t)out.size();
                     if (H[k].w1 & 1u) out.push_back(device_leaf(T, H[k]));
                     else {
-                        out.push_back(gigl::KdNode{H[k].w0, H[k].w1 & 6u});
+                        out.push_back(gigl::KdNode{H[k].w0, (H[k].w1 >> 1) & 3u});
                         (lv + 1 < levels ? nxt : frontier).push_back(Item{k, slot});
                     }
                 }
@@ -1177,6 +1188,11 @@ int gigl_scene_create(const float* verts, uint32_t n_verts, const uint32_t* tris
     // ---- device node array: same topology, cache-line treelet order (see flatten_nodes) ----
     std::vector<gigl::KdNode> dn;
     flatten_nodes(s->tree, treelet_levels, dn);
+    // device node word 1 keeps 29 bits for a triangle id / leaf size and 29 for a node slot
+    if (n_tris > kLeafPayload || dn.size() >= (1u << 29) || s->tree.leaf_prim_ids.size() > kLeafPayload) {
+        delete s;
+        return fail(GIGL_ERR_TOO_LARGE, "scene exceeds the device node encoding (2^29 triangles / node slots)");
+    }
     const size_t nb_nodes = std::max<size_t>(dn.size(), 2) * sizeof(uint2);
     const size_t nb_leaf = std::max<size_t>(s->tree.leaf_prim_ids.size(), 1) * 4;
     const size_t nb_tris = std::max<size_t>(rec.size(), 16) * 4;

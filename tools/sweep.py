@@ -73,11 +73,15 @@ def main():
             rt.set_option("stats", pseudo["stats"])
             o, d = (s_o, s_d) if pseudo["sorted"] else (d_o, d_d)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            if pseudo["any"]:
-                scene.trace_any_device(o.data_ptr(), d.data_ptr(), n, bits.data_ptr(), sh)
-            else:
-                scene.trace_closest_device(o.data_ptr(), d.data_ptr(), n, hits.data_ptr(), sh)
+            # the first of the two launches is untimed: a variant with a different grid makes the
+            # stream-ordered pool allocate a new workspace block, which costs ~0.5 ms once
+            for rep in range(2):
+                if rep == 1:
+                    e0.record()
+                if pseudo["any"]:
+                    scene.trace_any_device(o.data_ptr(), d.data_ptr(), n, bits.data_ptr(), sh)
+                else:
+                    scene.trace_closest_device(o.data_ptr(), d.data_ptr(), n, hits.data_ptr(), sh)
             e1.record()
             torch.cuda.synchronize()
             if r > 0:
