@@ -26,12 +26,17 @@
 
 // A/B switches kept from tuning (tools/sweep.py over builds, same device, interleaved): the
 // branch-free child-order predicate is worth 1-3 %; the branch-free triangle test costs 10 VGPRs,
-// drops the kernel from 6 to 5 waves/SIMD and loses 4-10 % on coherent batches.
+// drops the kernel from 6 to 5 waves/SIMD and loses 4-10 % on coherent batches.  GIGL_EARLY_PAIR requests
+// both children of a node before the step is decided (+14 % on coherent batches, +1.5 % on the
+// incoherent bench batch, which is bound by the chip's L2-miss rate instead).
 #ifndef GIGL_BRANCHLESS_TRI
 #define GIGL_BRANCHLESS_TRI 0
 #endif
 #ifndef GIGL_BRANCHLESS_STEP
 #define GIGL_BRANCHLESS_STEP 1
+#endif
+#ifndef GIGL_EARLY_PAIR
+#define GIGL_EARLY_PAIR 1
 #endif
 
 #include <cfloat>
@@ -414,6 +419,11 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
             if (is_t) {
                 const unsigned axis = nd.y & 3u;
                 const unsigned pair = nd.y >> 2;   // slot of the bottom child; the top child is the next slot
+#if GIGL_EARLY_PAIR
+                // both children (one aligned 16-byte pair) are requested before the step is decided,
+                // so the decision's arithmetic overlaps the memory round trip
+                const uint4 kids = *reinterpret_cast<const uint4*>(P.nodes + pair);
+#endif
                 const float split = __uint_as_float(nd.x);
                 const float oa = sel3(axis, r.ox, r.oy, r.oz);
                 const float ia = sel3(axis, r.ix, r.iy, r.iz);
@@ -434,8 +444,12 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
                     push(t_split, pair + (bottom_first ? 1u : 0u));
                     r.tmax = t_split + eps_of(t_split);
                 }
+#if GIGL_EARLY_PAIR
+                nd = (bottom_first == take_second) ? make_uint2(kids.z, kids.w) : make_uint2(kids.x, kids.y);
+#else
                 node = pair + (bottom_first == take_second ? 1u : 0u);
                 nd = P.nodes[node];
+#endif
             }
             if ((int)__popcll(m_t) < t_exit) break;
         }
