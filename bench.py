@@ -178,14 +178,16 @@ def main():
                              "single-thread on the first 2^%d rays: %.4f Mrays/s"
                              % (int(np.log2(nm)), int(np.log2(n1)), cpu1),
                    "single_thread_mrays_s": round(cpu1, 4)}
-        if bytes_per_ray is None:
+        default_workload = args.tess == 158 and args.rays_log2 == 24
+        if bytes_per_ray is None and default_workload:
             # counters measured on the N=1 run of the same workload (profiles/); used when the CPU leg is skipped
             bytes_per_ray = 32.0 + 16.0 + 8.0 * 61.06 + 56.0 * 7.72
         k_ms = float(np.mean(kern_ms))
-        achieved = bytes_per_ray * n / (k_ms * 1e-3) / 1e9   # per GPU: one launch sequence over this rank's rays
+        # per GPU: one launch sequence over this rank's rays (None: a non-default workload without counters)
+        achieved = bytes_per_ray * n / (k_ms * 1e-3) / 1e9 if bytes_per_ray is not None else None
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tp):
+        if os.path.exists(tp) and default_workload:
             try:
                 traffic = json.load(open(tp)).get("trace_closest_hbm_bytes_per_launch")
             except Exception:
@@ -201,10 +203,11 @@ def main():
                                       if gather else ""),
                        "triangles": int(len(T)), "rays_per_gpu": int(n), "tree_build_ms": round(st.build_ms, 1),
                        "tree_device_bytes": int(st.device_bytes), "setup_s": round(setup_s, 1)},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+            "roofline": {"bound": "hbm", "achieved": None if achieved is None else round(achieved, 2),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "kernel": "trace_kernel<closest>", "kernel_ms": round(k_ms, 4),
-                         "algorithmic_bytes_per_ray": round(bytes_per_ray, 2),
+                         "algorithmic_bytes_per_ray": None if bytes_per_ray is None else round(bytes_per_ray, 2),
                          "mean_nodes_visited": mean_nodes, "mean_triangle_tests": mean_tris},
             "cpu_baseline": cpu,
             "parity": parity,
