@@ -273,6 +273,43 @@ def extras(torch, rt, S, scene, d_o, d_d, n, device):
     pi = torch.empty((64, 1024, 1024), dtype=torch.float32, device=device)
     ms = timeit(lambda: cs.compute_pi_density_device(fog, cam, 1024, 1024, pi.data_ptr(), sh), reps=2)
     res["compute_pi_density_1024_ms"] = round(ms, 3)   # reference: 3.1 s on 8 CPU threads
+    # one frame of the software shading stage (Surface.frag + tone mapping) over the Cornell config:
+    # 1 primary light + the golden 150-VPL set, visibility and transmittance from the shadow batch
+    vp = np.load(os.path.join(ROOT, "tests", "golden", "vpl_set.npz"))["vpls"]
+    ppls = np.zeros((1, 8), np.float32)
+    ppls[0, :3], ppls[0, 4:7] = S.PRIM_PL_POS, S.PRIM_PL_INTENS
+    l151 = np.concatenate([ppls[:, :3], vp.view(np.float32)[:, :3]]).astype(np.float32)
+    _, _, mats, _ = S.load_obj(os.path.join(ROOT, "tests", "golden", "cornell_box.obj"))
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    d_l, d_ppl, d_vpl, d_mat = up(l151), up(ppls), up(vp.view(np.int32)), up(mats)
+    npair = npix * 151
+    sb = torch.zeros((npair + 63) // 64, dtype=torch.int64, device=device)
+    tr = torch.empty(npair, dtype=torch.float32, device=device)
+    accum = torch.zeros((npix, 4), dtype=torch.float32, device=device)
+    rgb = torch.zeros((npix, 3), dtype=torch.float32, device=device)
+    prm = rt.ShadeParams()
+    prm.cam_pos[:] = S.CAM_POS
+    prm.res_x = prm.res_y = 1024
+    prm.first, prm.n_ppls, prm.n_vpls = 0, 1, 150
+    prm.gi_enabled, prm.clamp_rsq, prm.frame_id, prm.pi_res_z = 1, 1, 0, 64
+    prm.sca_albedo = float(np.float32(S.SCA_K) / (np.float32(S.ABS_K) + np.float32(S.SCA_K)))
+
+    def shade():
+        cs.shade_surface_device(prm, po.data_ptr(), pd.data_ptr(), ph.data_ptr(), npix, d_mat.data_ptr(), len(mats),
+                                d_ppl.data_ptr(), d_vpl.data_ptr(), sb.data_ptr(), accum.data_ptr(), fog=fog,
+                                transm_ptr=tr.data_ptr(), pi_dens_ptr=pi.data_ptr(), stream=sh)
+        rt.tonemap_device(accum.data_ptr(), npix, 0, 12, rgb.data_ptr(), device=device.index, stream=sh)
+
+    def frame():
+        cs.trace_primary_device(cam, 1024, 0, npix, ph.data_ptr(), sh)
+        cs.shadow_batch_device(po.data_ptr(), pd.data_ptr(), ph.data_ptr(), npix, d_l.data_ptr(), 151, sb.data_ptr(),
+                               fog=fog, transm_ptr=tr.data_ptr(), stream=sh)
+        shade()
+
+    frame()
+    res["cornell_shade_surface_ms"] = round(timeit(shade, reps=2), 3)
+    res["cornell_frame_ms"] = round(timeit(frame, reps=2), 3)   # primary + 151 shadow rays/pixel + march + shade
+    res["cornell_frame_mean_rgb"] = [round(float(x), 5) for x in rgb.mean(0).tolist()]
     fog.close()
     cs.close()
     return res

@@ -746,6 +746,200 @@ __global__ void __launch_bounds__(256) pi_density_kernel(FogParams F, Cam12 cam,
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// software shading stage: Surface.frag main() (Source/Shaders/Surface.frag:290-343) and
+// Combine.frag's normalisation + tone mapping (:72-76) as compute kernels over the hit buffers,
+// occlusion bits and transmittance the ray batches produce.  Stand-ins for the GL pipeline are
+// listed in DESIGN.md "Shading stage"; the arithmetic mirrors oracle/gigl_oracle.cpp step by step.
+// ------------------------------------------------------------------------------------------
+struct F3 { float x, y, z; };
+__device__ __forceinline__ F3 f3(float x, float y, float z) { return F3{x, y, z}; }
+__device__ __forceinline__ F3 ld3(const float* p) { return F3{p[0], p[1], p[2]}; }
+__device__ __forceinline__ F3 operator+(F3 a, F3 b) { return F3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ F3 operator-(F3 a, F3 b) { return F3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ F3 operator-(F3 a) { return F3{-a.x, -a.y, -a.z}; }
+__device__ __forceinline__ F3 operator*(F3 a, F3 b) { return F3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+__device__ __forceinline__ F3 operator*(F3 a, float k) { return F3{a.x * k, a.y * k, a.z * k}; }
+__device__ __forceinline__ F3 operator*(float k, F3 a) { return F3{k * a.x, k * a.y, k * a.z}; }
+__device__ __forceinline__ float dot3(F3 a, F3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ float len3(F3 v) { return sqrtf(v.x * v.x + v.y * v.y + v.z * v.z); }
+__device__ __forceinline__ F3 norm3(F3 v) { return v * (1.0f / sqrtf(v.x * v.x + v.y * v.y + v.z * v.z)); }
+__device__ __forceinline__ F3 cross3(F3 a, F3 b) {
+    return F3{a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y};
+}
+
+// phongBRDF, Surface.frag:205-217
+__device__ __forceinline__ F3 phong_brdf(F3 I, F3 N, F3 O, F3 k_d, F3 k_s, float n_s) {
+    F3 brdf = k_d;
+    if (n_s > 0.0f) {
+        const F3 mI = -I;
+        const F3 S = mI - (2.0f * dot3(N, mI)) * N;   // reflect(-I, N)
+        const float c = dot3(O, S);
+        if (c > 0.0f) brdf = brdf + k_s * powf(c, n_s);
+    }
+    return brdf;
+}
+// evalPhaseHG, Surface.frag:219-223
+__device__ __forceinline__ float phase_hg(float cos_the) {
+    const float g = 0.25f;
+    const float base = 1.0f + g * g - 2.0f * g * cos_the;
+    return 0.25f * 0.318309873f * (1.0f - g * g) / (base * sqrtf(base));
+}
+// computeLe, Surface.frag:225-242.  v: one 96-byte VPL record as 24 words (PointLight.h:66-77)
+__device__ __forceinline__ F3 compute_le(const float* v, F3 O, float sca_albedo) {
+    const unsigned type = __float_as_uint(v[3]);
+    if (type == 1u) return (phase_hg(dot3(O, ld3(v + 8))) * sca_albedo) * ld3(v + 4);
+    if (type == 2u) {
+        const F3 w_norm = ld3(v + 12);
+        const float cos_out = smax(0.0f, dot3(O, w_norm));
+        return (phong_brdf(ld3(v + 8), w_norm, O, ld3(v + 16), ld3(v + 20), v[23]) * ld3(v + 4)) * cos_out;
+    }
+    return f3(0.0f, 0.0f, 0.0f);
+}
+
+struct ShadeParams {
+    float cam[3];
+    unsigned res_x, res_y, first, n_pts, n_ppls, n_vpls;
+    int gi_enabled, clamp_rsq, frame_id, pi_res_z;
+    float sca_albedo;
+    const float4* prim_o;
+    const float4* prim_d;
+    const uint4* hits;
+    const float4* tris;
+    const float* materials;          // 12 floats per material: k_d, pad, k_s, n_s, k_e, pad (RTBase.h:72-77)
+    const float* ppls;               // 8 floats per light: w_pos, pad, intens, pad (std140)
+    const float* vpls;               // 24 words per light
+    const unsigned long long* bits;  // shadow batch occlusion bits, pair = point * n_lights + light
+    const float* transm;             // shadow batch transmittance per pair, or NULL
+    const float* pi_dens;            // computePiDensity's output, or NULL without fog
+    float4* accum;
+    float2* fog_dist;
+};
+
+constexpr int kShadeTile = 16;   // lights per transmittance tile
+
+// One pixel per lane, lights in the reference's order (primary lights, then VPLs).  The pair-major
+// transmittance array is read through a 256 x 16 LDS tile so that the global loads are coalesced.
+__global__ void __launch_bounds__(256) shade_surface_kernel(FogParams F, ShadeParams S) {
+    __shared__ float s_tr[256 * (kShadeTile + 1)];
+    const unsigned tid = threadIdx.x;
+    const unsigned pt0 = blockIdx.x * 256u, pt = pt0 + tid;
+    const unsigned n_lights = S.n_ppls + S.n_vpls;
+    const bool in_range = pt < S.n_pts;
+    F3 col = f3(0.0f, 0.0f, 0.0f);
+    float f_min = 0.0f, f_max = 0.0f, transm_frag = 1.0f;
+    bool lit = false;
+    F3 w_pos = col, N = col, O = col, k_d = col, k_s = col, d = col;
+    float n_s = 0.0f;
+    uint4 h = make_uint4(kMiss, 0u, 0u, 0u);
+    if (in_range) h = S.hits[pt];
+    if (in_range && S.frame_id < 30 && h.x != kMiss) {                       // Surface.frag:292
+        const float4 o4 = S.prim_o[pt], d4 = S.prim_d[pt];
+        d = f3(d4.x, d4.y, d4.z);
+        w_pos = f3(o4.x, o4.y, o4.z) + __uint_as_float(h.y) * d;
+        const F3 cam = f3(S.cam[0], S.cam[1], S.cam[2]);
+        const F3 ray_d = norm3(w_pos - cam);                                 // :296
+        if (F.ext_k > 0.0f) {                                                // :297-315
+            const float t_frag = len3(w_pos - cam);
+            const float ivx = 1.0f / ray_d.x, ivy = 1.0f / ray_d.y, ivz = 1.0f / ray_d.z;
+            float t0 = (F.mnx - cam.x) * ivx, t1 = (F.mxx - cam.x) * ivx;
+            float t_min = smin(t0, t1), t_max = smax(t0, t1);
+            t0 = (F.mny - cam.y) * ivy; t1 = (F.mxy - cam.y) * ivy;
+            t_min = smax(t_min, smin(t0, t1)); t_max = smin(t_max, smax(t0, t1));
+            t0 = (F.mnz - cam.z) * ivz; t1 = (F.mxz - cam.z) * ivz;
+            t_min = smax(t_min, smin(t0, t1)); t_max = smin(t_max, smax(t0, t1));
+            if (t_max > smax(t_min, 0.0f) && t_min < t_frag) {
+                t_min = smax(t_min, 0.0f);
+                t_max = smin(t_max, t_frag);
+                const unsigned pix = S.first + pt;
+                const unsigned px = pix % S.res_x, py = pix / S.res_x;
+                const float z = (t_frag - t_min) / (t_max - t_min);
+                // texture(pi_dens): nearest in x,y, linear in z, CLAMP_TO_EDGE (DensityField.cpp:376-382)
+                float tz = z * (float)S.pi_res_z - 0.5f;
+                tz = smin(smax(tz, 0.0f), (float)(S.pi_res_z - 1));
+                const float fz = floorf(tz);
+                const int z0 = (int)fz, z1 = z0 + 1 < S.pi_res_z ? z0 + 1 : S.pi_res_z - 1;
+                const float f = tz - fz;
+                const size_t plane = (size_t)S.res_x * S.res_y, at = px + (size_t)py * S.res_x;
+                const float a = S.pi_dens[at + (size_t)z0 * plane], b = S.pi_dens[at + (size_t)z1 * plane];
+                const float opt_depth = F.ext_k * ((1.0f - f) * a + f * b);
+                transm_frag = expf(-opt_depth);
+            } else {
+                t_min = t_max = 0.0f;
+            }
+            f_min = t_min; f_max = t_max;
+        }
+        if (transm_frag > 0.001f) {                                           // :316-318
+            lit = true;
+            const float4 ta = S.tris[kTriStride * (size_t)h.x], tb = S.tris[kTriStride * (size_t)h.x + 1];
+            const float4 tc = S.tris[kTriStride * (size_t)h.x + 2];
+            N = norm3(cross3(f3(ta.w, tb.x, tb.y), f3(tb.z, tb.w, tc.x)));
+            if (dot3(d, N) > 0.0f) N = -N;
+            const float* m = S.materials + 12 * (size_t)__float_as_uint(tc.y);
+            k_d = ld3(m); k_s = ld3(m + 4); n_s = m[7];
+            O = -ray_d;
+        }
+    }
+    for (unsigned l0 = 0; l0 < n_lights; l0 += kShadeTile) {
+        if (S.transm) {
+            for (unsigned k = 0; k < (unsigned)kShadeTile; ++k) {
+                const unsigned idx = tid + k * 256u, p = idx / kShadeTile, l = idx % kShadeTile;
+                float v = 1.0f;
+                if (pt0 + p < S.n_pts && l0 + l < n_lights) v = S.transm[(size_t)(pt0 + p) * n_lights + l0 + l];
+                s_tr[p * (kShadeTile + 1) + l] = v;
+            }
+            __syncthreads();
+        }
+        if (lit) {
+            const unsigned l_end = l0 + kShadeTile < n_lights ? l0 + kShadeTile : n_lights;
+            for (unsigned l = l0; l < l_end; ++l) {
+                const bool is_ppl = l < S.n_ppls;
+                if (is_ppl ? !S.clamp_rsq : !S.gi_enabled) continue;                  // :319, :325
+                const size_t pair = (size_t)pt * n_lights + l;
+                if ((S.bits[pair >> 6] >> (pair & 63u)) & 1ull) continue;             // visibility > 0.0
+                const float* v = S.vpls + 24 * (size_t)(is_ppl ? 0u : l - S.n_ppls);
+                const F3 L = is_ppl ? ld3(S.ppls + 8 * l) : ld3(v);
+                const F3 dd = w_pos - L;
+                const float dist_sq = dot3(dd, dd);
+                const F3 I = norm3(-dd);
+                const float tr = S.transm ? s_tr[tid * (kShadeTile + 1) + (l - l0)] : 1.0f;
+                F3 Li;
+                if (is_ppl) {                                                          // :255-258
+                    const float falloff = 1.0f / dist_sq;
+                    Li = (tr * ld3(S.ppls + 8 * l + 4)) * falloff;
+                } else {                                                               // :278-281
+                    const float falloff = 1.0f / smax(dist_sq, 75.0f * 75.0f);
+                    Li = (tr * compute_le(v, -I, S.sca_albedo)) * falloff;
+                }
+                const float cos_inc = smax(0.0f, dot3(I, N));
+                const F3 c = (phong_brdf(I, N, O, k_d, k_s, n_s) * Li) * cos_inc;
+                col = col + transm_frag * c;                                           // :322, :328
+            }
+        }
+        if (S.transm) __syncthreads();
+    }
+    if (in_range && S.frame_id < 30) {
+        if (S.frame_id > 0) {                                                          // :332-337
+            const float4 a = S.accum[pt];
+            col.x += a.x; col.y += a.y; col.z += a.z;
+        }
+        S.accum[pt] = make_float4(col.x, col.y, col.z, 1.0f);                          // :339
+        if (S.fog_dist && F.ext_k > 0.0f) S.fog_dist[pt] = make_float2(f_min, f_max);  // recordRayDist, :314
+    }
+}
+
+// Combine.frag:72-76 (without the volume term)
+__global__ void __launch_bounds__(256) tonemap_kernel(const float4* __restrict__ accum, unsigned n, int frame_id,
+                                                      int exposure, float* __restrict__ rgb) {
+    const float div = (float)(1 + (frame_id < 30 ? frame_id : 30));
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const float4 a = accum[i];
+        rgb[3 * (size_t)i] = 1.0f - expf(-(float)exposure * (a.x / div));
+        rgb[3 * (size_t)i + 1] = 1.0f - expf(-(float)exposure * (a.y / div));
+        rgb[3 * (size_t)i + 2] = 1.0f - expf(-(float)exposure * (a.z / div));
+    }
+}
+
 __global__ void __launch_bounds__(256) sample_density_kernel(FogParams F, const float* pos, unsigned n, float* out) {
     for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
         // computeNormPos: (pos - min) / dims, BBox.cpp:53-55
@@ -1483,6 +1677,59 @@ int gigl_shadow_batch_device(const gigl_scene* s, const void* prim_o_tmin, const
                            P, transm);
         HIP_TRY(hipGetLastError());
     }
+    return GIGL_OK;
+}
+
+int gigl_shade_surface_device(const gigl_scene* s, const gigl_fog* fog, const gigl_shade_params* prm,
+                              const void* prim_o_tmin, const void* prim_d_tmax, const gigl_hit* prim_hits,
+                              uint64_t n_pts, const float* materials, uint32_t n_materials, const float* ppls,
+                              const void* vpls, const uint64_t* occluded_bits, const float* transm,
+                              const float* pi_dens, float* accum_rgba, float* fog_dist, void* stream) {
+    if (!s || !prm) return fail(GIGL_ERR_INVALID, "scene or params is NULL");
+    if (s->device == GIGL_DEVICE_NONE) return fail(GIGL_ERR_NO_DEVICE, "host-only scene: no device to shade on");
+    if (n_pts == 0) return GIGL_OK;
+    if (!prim_o_tmin || !prim_d_tmax || !prim_hits || !accum_rgba) return fail(GIGL_ERR_INVALID, "NULL input");
+    if (prm->n_ppls < 0 || prm->n_vpls < 0) return fail(GIGL_ERR_INVALID, "negative light count");
+    const uint64_t n_lights = (uint64_t)prm->n_ppls + (uint64_t)prm->n_vpls;
+    if (n_lights > 0 && (!occluded_bits || !materials || n_materials == 0))
+        return fail(GIGL_ERR_INVALID, "lights given without occlusion bits or materials");
+    if ((prm->n_ppls > 0 && !ppls) || (prm->n_vpls > 0 && !vpls)) return fail(GIGL_ERR_INVALID, "NULL light array");
+    if (n_pts > kMaxRays || n_pts * (n_lights ? n_lights : 1) > kMaxRays)
+        return fail(GIGL_ERR_TOO_LARGE, "n_pts * n_lights must stay below 0xF0000000");
+    if (prm->res_x <= 0 || prm->res_y <= 0 || prm->first + n_pts > (uint64_t)prm->res_x * (uint64_t)prm->res_y)
+        return fail(GIGL_ERR_INVALID, "pixel range outside the image");
+    if (fog && fog->device != s->device) return fail(GIGL_ERR_INVALID, "fog and scene live on different devices");
+    if (fog && fog->fp.ext_k > 0.0f && (!pi_dens || prm->pi_res_z <= 0))
+        return fail(GIGL_ERR_INVALID, "fog given without a preintegrated density volume");
+    if (transm && !fog) return fail(GIGL_ERR_INVALID, "transm given without fog");
+    DeviceGuard g(s->device);
+    FogParams F = {};
+    if (fog) F = fog->fp;
+    ShadeParams S = {};
+    for (int a = 0; a < 3; ++a) S.cam[a] = prm->cam_pos[a];
+    S.res_x = (unsigned)prm->res_x; S.res_y = (unsigned)prm->res_y; S.first = (unsigned)prm->first;
+    S.n_pts = (unsigned)n_pts; S.n_ppls = (unsigned)prm->n_ppls; S.n_vpls = (unsigned)prm->n_vpls;
+    S.gi_enabled = prm->gi_enabled; S.clamp_rsq = prm->clamp_rsq; S.frame_id = prm->frame_id;
+    S.pi_res_z = prm->pi_res_z; S.sca_albedo = prm->sca_albedo;
+    S.prim_o = (const float4*)prim_o_tmin; S.prim_d = (const float4*)prim_d_tmax; S.hits = (const uint4*)prim_hits;
+    S.tris = s->d_tris; S.materials = materials; S.ppls = ppls; S.vpls = (const float*)vpls;
+    S.bits = (const unsigned long long*)occluded_bits; S.transm = transm; S.pi_dens = pi_dens;
+    S.accum = (float4*)accum_rgba; S.fog_dist = (float2*)fog_dist;
+    hipLaunchKernelGGL(shade_surface_kernel, dim3((unsigned)((n_pts + 255) / 256)), dim3(256), 0, (hipStream_t)stream, F, S);
+    HIP_TRY(hipGetLastError());
+    return GIGL_OK;
+}
+
+int gigl_tonemap_device(int device, const float* accum_rgba, uint64_t n, int frame_id, int exposure, float* rgb_out,
+                        void* stream) {
+    if (n == 0) return GIGL_OK;
+    if (!accum_rgba || !rgb_out) return fail(GIGL_ERR_INVALID, "NULL argument");
+    if (n > kMaxRays) return fail(GIGL_ERR_TOO_LARGE, "at most 0xF0000000 pixels per call");
+    DeviceGuard g(device);
+    if (!g.ok) return fail(GIGL_ERR_NO_DEVICE, "hipSetDevice failed");
+    hipLaunchKernelGGL(tonemap_kernel, dim3(stream_grid(nullptr, n)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)accum_rgba, (unsigned)n, frame_id, exposure, rgb_out);
+    HIP_TRY(hipGetLastError());
     return GIGL_OK;
 }
 

@@ -24,7 +24,8 @@ SYMBOLS = [
     "gigl_trace_any_device", "gigl_trace_any", "gigl_trace_one", "gigl_camera_setup",
     "gigl_gen_primary_rays_device", "gigl_trace_primary_device", "gigl_shadow_batch_device", "gigl_fog_create",
     "gigl_fog_destroy", "gigl_transmittance_device", "gigl_sample_density", "gigl_debug_rescaled_eps",
-    "gigl_set_option", "gigl_debug_last_stats", "gigl_compute_pi_density_device",
+    "gigl_set_option", "gigl_debug_last_stats", "gigl_compute_pi_density_device", "gigl_shade_surface_device",
+    "gigl_tonemap_device",
 ]
 
 
@@ -32,6 +33,13 @@ class GiglError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("gigl_rt error %d: %s" % (code, msg))
         self.code = code
+
+
+class ShadeParams(C.Structure):
+    """gigl_shade_params (include/gigl_rt.h)."""
+    _fields_ = [("cam_pos", C.c_float * 3), ("res_x", C.c_int), ("res_y", C.c_int), ("first", C.c_uint64),
+                ("n_ppls", C.c_int), ("n_vpls", C.c_int), ("gi_enabled", C.c_int), ("clamp_rsq", C.c_int),
+                ("frame_id", C.c_int), ("pi_res_z", C.c_int), ("sca_albedo", C.c_float)]
 
 
 class TreeStats(C.Structure):
@@ -82,6 +90,8 @@ def lib():
         L.gigl_set_option.argtypes = [C.c_char_p, i]
         L.gigl_debug_last_stats.argtypes = [vp]
         L.gigl_compute_pi_density_device.argtypes = [vp, vp, vp, i, i, vp, vp]
+        L.gigl_shade_surface_device.argtypes = [vp, vp, vp, vp, vp, vp, u64, vp, u32, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.gigl_tonemap_device.argtypes = [i, vp, u64, i, i, vp, vp]
         for s in SYMBOLS:
             if s != "gigl_last_error":
                 getattr(L, s).restype = C.c_int
@@ -132,6 +142,11 @@ def debug_rescaled_eps(t, device=0):
     out = np.zeros_like(t)
     _check(lib().gigl_debug_rescaled_eps(device, _p(t), t.size, _p(out)))
     return out
+
+
+def tonemap_device(accum_ptr, n, frame_id, exposure, rgb_ptr, device=0, stream=0):
+    """Combine.frag:72-76 without the volume term."""
+    _check(lib().gigl_tonemap_device(device, accum_ptr, n, frame_id, exposure, rgb_ptr, stream))
 
 
 def unpack_bits(words, n):
@@ -225,6 +240,15 @@ class Scene:
     def compute_pi_density_device(self, fog, cam, res_x, res_y, out_ptr, stream=0):
         """DensityField::computePiDensity as one GPU batch (Source/Fog/DensityField.cpp:271-327)."""
         _check(lib().gigl_compute_pi_density_device(self.h, fog.h, _p(_f32(cam)), res_x, res_y, out_ptr, stream))
+
+    def shade_surface_device(self, prm, o_ptr, d_ptr, hits_ptr, n_pts, materials_ptr, n_materials, ppls_ptr,
+                             vpls_ptr, bits_ptr, accum_ptr, fog=None, transm_ptr=None, pi_dens_ptr=None,
+                             fog_dist_ptr=None, stream=0):
+        """Surface.frag main() as a compute kernel (Source/Shaders/Surface.frag:290-343); prm: ShadeParams."""
+        _check(lib().gigl_shade_surface_device(self.h, fog.h if fog is not None else None, C.byref(prm), o_ptr,
+                                               d_ptr, hits_ptr, n_pts, materials_ptr, n_materials, ppls_ptr,
+                                               vpls_ptr, bits_ptr, transm_ptr, pi_dens_ptr, accum_ptr,
+                                               fog_dist_ptr, stream))
 
     def shadow_batch_device(self, o_ptr, d_ptr, hits_ptr, n_pts, lights_ptr, n_lights, bits_ptr, fog=None,
                             transm_ptr=None, stream=0):

@@ -137,6 +137,39 @@ int gigl_shadow_batch_device(const gigl_scene* s, const void* prim_o_tmin, const
                              uint32_t n_lights, uint64_t* occluded_bits, const gigl_fog* fog,
                              float* transm, void* stream);
 
+/* Software shading stage ("next" row of the scope table): Surface.frag main()
+ * (Source/Shaders/Surface.frag:290-343) for one frame over pixels [first, first+n_pts), consuming
+ * the primary hit records, the shadow batch's occlusion bits and transmittance, and
+ * computePiDensity's volume.  Lights are the n_ppls primary lights followed by the n_vpls VPLs, in
+ * the order the shadow batch's `lights` array listed their positions.  All pointers are device
+ * pointers except prm.  Stand-ins for the GL pipeline (G-buffer, shadow maps, texture filtering)
+ * are listed in DESIGN.md "Shading stage". */
+typedef struct gigl_shade_params {
+    float    cam_pos[3];      /* cam_w_pos */
+    int      res_x, res_y;    /* CAM_RES; pi_dens is res_x * res_y * pi_res_z */
+    uint64_t first;           /* index of the batch's first pixel, row-major */
+    int      n_ppls, n_vpls;  /* MAX_PPLS = 1, n_vpls <= MAX_VPLS = 150 in the reference */
+    int      gi_enabled, clamp_rsq, frame_id;
+    int      pi_res_z;
+    float    sca_albedo;      /* FogVolume::getScaAlbedo, Source/Fog/FogVolume.cpp:44-46 */
+} gigl_shade_params;
+/* materials: float[12*n_materials] = k_d, pad, k_s, n_s, k_e, pad (Source/RT/RTBase.h:72-77).
+ * ppls: float[8*n_ppls] = w_pos, pad, intens, pad (std140 PrimaryPointLight).
+ * vpls: n_vpls 96-byte VPL records (Source/VPL/PointLight.h:66-77).
+ * transm (optional, needs fog): per pair, as gigl_shadow_batch_device wrote it.
+ * pi_dens: required when fog is given with ext_k > 0.
+ * accum_rgba: float[4*n_pts], read when frame_id > 0, always written (writeToAccumBuffer).
+ * fog_dist (optional): float[2*n_pts] = recordRayDist's (t_min, t_max), written when ext_k > 0. */
+int gigl_shade_surface_device(const gigl_scene* s, const gigl_fog* fog, const gigl_shade_params* prm,
+                              const void* prim_o_tmin, const void* prim_d_tmax, const gigl_hit* prim_hits,
+                              uint64_t n_pts, const float* materials, uint32_t n_materials, const float* ppls,
+                              const void* vpls, const uint64_t* occluded_bits, const float* transm,
+                              const float* pi_dens, float* accum_rgba, float* fog_dist, void* stream);
+/* Combine.frag:72-76 without the volume term: rgb = 1 - exp(-exposure * accum / (1 + min(frame_id, 30))).
+ * rgb_out: float[3*n]. */
+int gigl_tonemap_device(int device, const float* accum_rgba, uint64_t n, int frame_id, int exposure,
+                        float* rgb_out, void* stream);
+
 /* DensityField data + FogVolume coefficients (Source/Fog/DensityField.cpp:177-211,
  * Source/Fog/FogVolume.cpp:32-36).  dens: res[0]*res[1]*res[2] bytes, x fastest; box = min, max. */
 int gigl_fog_create(const uint8_t* dens, const int res[3], const float box[6], float ext_k,

@@ -987,3 +987,140 @@ int ora_photon_trace(const ora_scene* s, const float* materials, uint32_t n_mat,
 }
 
 }  /* extern "C" */
+
+/* ---- software shading stage: Source/Shaders/Surface.frag:205-343, Combine.frag:62-77 ---------
+ * PARITY UNPINNED: GLSL cannot run here.  Stand-ins for the GL pipeline, all stated in DESIGN.md
+ * "Shading stage": the G-buffer position is the primary hit point o + t*d, the G-buffer normal is
+ * the geometric normal turned to face the camera, shadow-map visibility is the any-hit result of
+ * the shadow batch, texture(pi_dens) is nearest in x,y (pixel centre = texel centre) and linear in
+ * z with edge clamping (DensityField.cpp:376-382). */
+namespace {
+struct VPL96 { float w_pos[3]; uint type; float intens[3]; float sca_k; float w_inc[3]; uint path_id;
+               float w_norm[3]; uint pad1; float k_d[3]; uint pad2; float k_s[3]; float n_s; };
+inline V3 ld3(const float* p) { return v3(p[0], p[1], p[2]); }
+/* phongBRDF, Surface.frag:205-217; reflect(I,N) = I - 2*dot(N,I)*N */
+inline V3 glsl_phong_brdf(V3 I, V3 N, V3 O, V3 k_d, V3 k_s, float n_s) {
+    V3 brdf = k_d;
+    if (n_s > 0.0f) {
+        const V3 mI = -I;
+        const V3 S = mI - (2.0f * dot(N, mI)) * N;
+        const float c = dot(O, S);
+        if (c > 0.0f) brdf = brdf + k_s * powf(c, n_s);
+    }
+    return brdf;
+}
+/* evalPhaseHG, Surface.frag:219-223 */
+inline float glsl_phase_hg(float cos_the) {
+    const float g = 0.25f;
+    const float base = 1.0f + g * g - 2.0f * g * cos_the;
+    return 0.25f * 0.318309873f * (1.0f - g * g) / (base * sqrtf(base));
+}
+/* computeLe, Surface.frag:225-242 */
+inline V3 glsl_compute_le(const VPL96& v, V3 O, float sca_albedo) {
+    if (v.type == 1u) return (glsl_phase_hg(dot(O, ld3(v.w_inc))) * sca_albedo) * ld3(v.intens);
+    if (v.type == 2u) {
+        const float cos_out = smax(0.0f, dot(O, ld3(v.w_norm)));
+        return (glsl_phong_brdf(ld3(v.w_inc), ld3(v.w_norm), O, ld3(v.k_d), ld3(v.k_s), v.n_s) * ld3(v.intens)) * cos_out;
+    }
+    return v3(0.0f, 0.0f, 0.0f);
+}
+inline float pi_dens_fetch(const float* pi, int res_x, int res_y, int res_z, int x, int y, float z) {
+    const size_t plane = (size_t)res_x * res_y;
+    float tz = z * (float)res_z - 0.5f;
+    tz = smin(smax(tz, 0.0f), (float)(res_z - 1));                   /* CLAMP_TO_EDGE */
+    const float fz = floorf(tz);
+    const int z0 = (int)fz, z1 = z0 + 1 < res_z ? z0 + 1 : res_z - 1;
+    const float f = tz - fz;
+    const float a = pi[x + (size_t)y * res_x + (size_t)z0 * plane], b = pi[x + (size_t)y * res_x + (size_t)z1 * plane];
+    return (1.0f - f) * a + f * b;
+}
+}  // namespace
+
+extern "C" {
+
+void ora_shade_surface(const ora_scene* s, const ora_fog* fog, const float cam_pos[3], int res_x, int res_y,
+                       uint64_t first, const float* po, const float* pd, const void* prim_hits16, uint64_t n_pts,
+                       const float* materials, const float* ppls, uint32_t n_ppls, const void* vpls,
+                       uint32_t n_vpls, const uint8_t* occluded, const float* transm, const float* pi_dens,
+                       int pi_res_z, float sca_albedo, int gi_enabled, int clamp_rsq, int frame_id,
+                       float* accum_rgba, float* fog_dist, int n_threads) {
+    const Hit16* H = (const Hit16*)prim_hits16;
+    const VPL96* V = (const VPL96*)vpls;
+    const uint32_t n_lights = n_ppls + n_vpls;
+    const V3 cam = ld3(cam_pos);
+    const float ext_k = fog ? fog->ext_k : 0.0f;
+    const int nt = n_threads < 1 ? 1 : n_threads;
+    (void)nt;
+#pragma omp parallel for schedule(dynamic, 256) num_threads(nt) if (nt > 1)
+    for (int64_t i = 0; i < (int64_t)n_pts; ++i) {
+        V3 col = v3(0.0f, 0.0f, 0.0f);
+        float f_min = 0.0f, f_max = 0.0f;
+        const Hit16 h = H[i];
+        if (frame_id < 30 && h.tri_id != 0xFFFFFFFFu) {                 /* Surface.frag:292 */
+            const V3 o = ld3(po + 4 * i), d = ld3(pd + 4 * i);
+            const V3 w_pos = o + h.t * d;
+            const V3 ray_d = normalize(w_pos - cam);                      /* :296 */
+            float transm_frag = 1.0f;
+            if (ext_k > 0.0f) {                                           /* :297-315 */
+                const float t_frag = length(w_pos - cam);
+                float t_min, t_max;
+                if (glsl_intersect_bbox(*fog, cam, ray_d, t_frag, t_min, t_max)) {
+                    t_min = smax(t_min, 0.0f);
+                    t_max = smin(t_max, t_frag);
+                    const uint64_t pix = first + (uint64_t)i;
+                    const float z = (t_frag - t_min) / (t_max - t_min);
+                    const float opt_depth = ext_k * pi_dens_fetch(pi_dens, res_x, res_y, pi_res_z,
+                                                                  (int)(pix % (uint64_t)res_x), (int)(pix / (uint64_t)res_x), z);
+                    transm_frag = expf(-opt_depth);
+                } else { t_min = t_max = 0.0f; }
+                f_min = t_min; f_max = t_max;
+            }
+            if (transm_frag > 0.001f) {                                    /* :316-331 */
+                const uint* ix = &s->tris[4 * (size_t)h.tri_id];
+                const V3 pt0 = s->verts[ix[0]];
+                V3 N = normalize(cross(s->verts[ix[1]] - pt0, s->verts[ix[2]] - pt0));
+                if (dot(d, N) > 0.0f) N = -N;
+                const float* m = materials + 12 * (size_t)ix[3];
+                const V3 k_d = ld3(m), k_s = ld3(m + 4);
+                const float n_s = m[7];
+                const V3 O = -ray_d;
+                for (uint32_t l = 0; l < n_lights; ++l) {
+                    const bool is_ppl = l < n_ppls;
+                    if (is_ppl ? !clamp_rsq : !gi_enabled) continue;
+                    if (occluded[(size_t)i * n_lights + l]) continue;     /* visibility > 0.0, :253/:276 */
+                    const V3 L = is_ppl ? ld3(ppls + 8 * l) : ld3(V[l - n_ppls].w_pos);
+                    const V3 dd = w_pos - L;
+                    const float dist_sq = dot(dd, dd);
+                    const V3 I = normalize(-dd);
+                    const float tr = transm ? transm[(size_t)i * n_lights + l] : 1.0f;
+                    V3 Li;
+                    if (is_ppl) {                                          /* :255-258 */
+                        const float falloff = 1.0f / dist_sq;
+                        Li = (tr * ld3(ppls + 8 * l + 4)) * falloff;
+                    } else {                                               /* :278-281 */
+                        const float falloff = 1.0f / smax(dist_sq, 75.0f * 75.0f);
+                        Li = (tr * glsl_compute_le(V[l - n_ppls], -I, sca_albedo)) * falloff;
+                    }
+                    const float cos_inc = smax(0.0f, dot(I, N));
+                    const V3 c = (glsl_phong_brdf(I, N, O, k_d, k_s, n_s) * Li) * cos_inc;
+                    col = col + transm_frag * c;                           /* :322, :328 */
+                }
+            }
+        }
+        if (frame_id < 30) {
+            float* a = accum_rgba + 4 * i;
+            if (frame_id > 0) { col.x += a[0]; col.y += a[1]; col.z += a[2]; }   /* :332-337 */
+            a[0] = col.x; a[1] = col.y; a[2] = col.z; a[3] = 1.0f;                /* :339 */
+            if (fog_dist && ext_k > 0.0f) { fog_dist[2 * i] = f_min; fog_dist[2 * i + 1] = f_max; }
+        }
+    }
+}
+
+/* Combine.frag:72-76 without the volume term: divide by the frame count, then tone-map. */
+void ora_tonemap(const float* accum_rgba, uint64_t n, int frame_id, int exposure, float* rgb) {
+    const float div = (float)(1 + (frame_id < 30 ? frame_id : 30));
+    for (uint64_t i = 0; i < n; ++i)
+        for (int c = 0; c < 3; ++c) rgb[3 * i + c] = 1.0f - expf(-(float)exposure * (accum_rgba[4 * i + c] / div));
+}
+
+}  /* extern "C" */

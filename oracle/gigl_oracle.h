@@ -127,6 +127,23 @@ int ora_photon_trace(const ora_scene* s, const float* materials, uint32_t n_mat,
                      uint64_t n_rng, void* vpls_out, uint32_t* n_paths_out,
                      uint64_t* n_rng_used_out);
 
+
+/* Software shading stage: Surface.frag main() (Source/Shaders/Surface.frag:290-343) for one frame over
+ * pixels [first, first+n_pts), and Combine.frag's normalisation + tone mapping (:72-76).  PARITY
+ * UNPINNED (GLSL cannot run here; stand-ins listed at the definition).  Lights are the n_ppls
+ * primary lights (ppls: 8 floats each = pos, pad, intens, pad, std140) followed by the n_vpls VPL
+ * records (96 B); occluded/transm are ora_shadow_batch's outputs for that light order.
+ * materials: float[12*n_mat] as ora_photon_trace.  accum_rgba: in-out float[4*n_pts];
+ * fog_dist (optional): float[2*n_pts] = recordRayDist's (t_min, t_max). */
+void ora_shade_surface(const ora_scene* s, const ora_fog* fog, const float cam_pos[3], int res_x, int res_y,
+                       uint64_t first, const float* prim_o_tmin, const float* prim_d_tmax,
+                       const void* prim_hits16, uint64_t n_pts, const float* materials, const float* ppls,
+                       uint32_t n_ppls, const void* vpls, uint32_t n_vpls, const uint8_t* occluded,
+                       const float* transm, const float* pi_dens, int pi_res_z, float sca_albedo,
+                       int gi_enabled, int clamp_rsq, int frame_id, float* accum_rgba, float* fog_dist,
+                       int n_threads);
+void ora_tonemap(const float* accum_rgba, uint64_t n, int frame_id, int exposure, float* rgb);
+
 #ifdef __cplusplus
 }
 #endif

@@ -68,6 +68,12 @@ def lib():
         L.ora_photon_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_float, C.c_float,
                                        C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                        C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ora_shade_surface.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint64,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
+                                        C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                        C.c_int]
+        L.ora_tonemap.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -239,3 +245,38 @@ def photon_trace(scene, materials, fog, abs_k, sca_k, maj_ext_k, fog_enabled, pp
                                _p(_f32(ppl_intens)), _p(_f32(shoot_dir)), max_vpl_count, _p(rng), len(rng),
                                _p(vpls), C.byref(n_paths), C.byref(n_used))
     return n, vpls, n_paths.value, n_used.value
+
+
+def shade_surface(scene, fog, cam_pos, res_x, res_y, first, ro, rd, hits, materials, ppls, vpls, occluded,
+                  transm=None, pi_dens=None, sca_albedo=0.0, gi_enabled=True, clamp_rsq=True, frame_id=0,
+                  accum=None, n_threads=1):
+    """Surface.frag main() for one frame (see ora_shade_surface).  ppls: (n_ppls, 8) floats; vpls:
+    VPL_DTYPE records; occluded/transm: (n_pts, n_ppls + n_vpls) from OracleScene.shadow_batch.
+    Returns (accum_rgba, fog_dist)."""
+    ro, rd = _f32(ro).reshape(-1, 4), _f32(rd).reshape(-1, 4)
+    hits = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
+    n = len(ro)
+    materials = _f32(materials).reshape(-1, 12)
+    ppls = _f32(ppls).reshape(-1, 8)
+    vpls = np.ascontiguousarray(vpls, dtype=VPL_DTYPE)
+    occluded = np.ascontiguousarray(occluded, dtype=np.uint8).reshape(n, len(ppls) + len(vpls))
+    if transm is not None:
+        transm = _f32(transm).reshape(n, len(ppls) + len(vpls))
+    pi_res_z = 0
+    if pi_dens is not None:
+        pi_dens = _f32(pi_dens)
+        pi_res_z = pi_dens.shape[0]
+    accum = np.zeros((n, 4), np.float32) if accum is None else _f32(accum).reshape(n, 4).copy()
+    fog_dist = np.zeros((n, 2), np.float32)
+    lib().ora_shade_surface(scene.h, fog.ref() if fog is not None else None, _p(_f32(cam_pos)), res_x, res_y, first,
+                            _p(ro), _p(rd), _p(hits), n, _p(materials), _p(ppls), len(ppls), _p(vpls), len(vpls),
+                            _p(occluded), _p(transm), _p(pi_dens), pi_res_z, sca_albedo, int(gi_enabled),
+                            int(clamp_rsq), frame_id, _p(accum), _p(fog_dist), n_threads)
+    return accum, fog_dist
+
+
+def tonemap(accum, frame_id, exposure):
+    accum = _f32(accum).reshape(-1, 4)
+    rgb = np.zeros((len(accum), 3), np.float32)
+    lib().ora_tonemap(_p(accum), len(accum), frame_id, exposure, _p(rgb))
+    return rgb

@@ -1,0 +1,66 @@
+"""CPU checks of the oracle's shading-stage restatement (ora_shade_surface, ora_tonemap): the
+properties Surface.frag's structure guarantees.  PARITY UNPINNED against the reference (no GLSL
+here, no reference image)."""
+import os
+
+import numpy as np
+
+from gigl_amd import scene_io as S
+from oracle import oracle_py as O
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _setup(cornell, oracle_cornell, density, fog_box, res=48):
+    cam = O.camera_setup(S.CAM_POS, S.CAM_DIR, S.CAM_UP, S.CAM_HFOV, res, res)
+    ro, rd = O.primary_rays(cam, res, 0, res * res)
+    hits = oracle_cornell.trace_closest(ro, rd, n_threads=4)
+    vp = np.load(os.path.join(GOLDEN, "vpl_set.npz"))
+    vpls = vp["vpls"].view(O.VPL_DTYPE).reshape(-1)
+    ppls = np.zeros((1, 8), np.float32)
+    ppls[0, :3], ppls[0, 4:7] = S.PRIM_PL_POS, S.PRIM_PL_INTENS
+    lights = np.concatenate([ppls[:, :3], vp["vpls"].view(np.float32)[:, :3]]).astype(np.float32)
+    ext_k = np.float32(S.ABS_K) + np.float32(S.SCA_K)
+    fog = O.Fog(density, fog_box, ext_k)
+    occ, tr = oracle_cornell.shadow_batch(ro, rd, hits, lights, fog=fog, want_transm=True, n_threads=4)
+    pi = O.compute_pi_density(oracle_cornell, fog, cam, res, res, n_threads=4)
+    return dict(res=res, ro=ro, rd=rd, hits=hits, vpls=vpls, ppls=ppls, occ=occ, tr=tr, pi=pi, fog=fog,
+                albedo=float(np.float32(S.SCA_K) / ext_k))
+
+
+def test_shade_surface_properties(cornell, oracle_cornell, density, fog_box):
+    c = _setup(cornell, oracle_cornell, density, fog_box)
+    res, n = c["res"], c["res"] ** 2
+    args = (oracle_cornell, c["fog"], S.CAM_POS, res, res, 0, c["ro"], c["rd"], c["hits"], cornell["materials"],
+            c["ppls"], c["vpls"], c["occ"])
+    kw = dict(transm=c["tr"], pi_dens=c["pi"], sca_albedo=c["albedo"], n_threads=4)
+    full, fd = O.shade_surface(*args, **kw)
+    assert full.shape == (n, 4) and (full[:, 3] == 1.0).all() and np.isfinite(full).all()
+    assert (full[:, :3] >= 0).all()
+    missed = c["hits"]["tri_id"] == 0xFFFFFFFF
+    assert missed.any() and (full[missed, :3] == 0).all() and (fd[missed] == 0).all()
+    assert (full[~missed, :3].sum(1) > 0).mean() > 0.9
+    # primary-light and VPL contributions are gated separately and add up (Surface.frag:319-330)
+    direct, _ = O.shade_surface(*args, gi_enabled=False, **kw)
+    indirect, _ = O.shade_surface(*args, clamp_rsq=False, **kw)
+    assert (direct[:, :3] <= full[:, :3] * (1 + 1e-5) + 1e-12).all()
+    assert np.allclose(direct[:, :3].astype(np.float64) + indirect[:, :3], full[:, :3], rtol=1e-4, atol=1e-9)
+    assert direct[:, :3].sum() > 0 and indirect[:, :3].sum() > 0
+    # fog only attenuates; without fog nothing is recorded in fog_dist
+    clear, fd0 = O.shade_surface(oracle_cornell, None, *args[2:], sca_albedo=c["albedo"], n_threads=4)
+    assert (fd0 == 0).all() and (clear[:, :3] >= full[:, :3] * (1 - 1e-5)).all()
+    assert (fd[:, 1] >= fd[:, 0]).all() and (fd[:, 1] > 0).any()
+    # frame accumulation (Surface.frag:332-339) and the frame cap (:292)
+    prev = np.random.default_rng(1).uniform(0, 3, (n, 4)).astype(np.float32)
+    acc, _ = O.shade_surface(*args, frame_id=2, accum=prev, **kw)
+    assert np.array_equal(acc[:, :3], full[:, :3] + prev[:, :3])
+    frozen, _ = O.shade_surface(*args, frame_id=30, accum=prev, **kw)
+    assert np.array_equal(frozen, prev)
+
+
+def test_tonemap():
+    a = np.array([[0, 1, 2, 1], [0.5, 0.25, 4, 1]], np.float32)
+    rgb = O.tonemap(a, 3, 2)
+    want = 1.0 - np.exp(-2.0 * a[:, :3].astype(np.float64) / 4.0)
+    assert np.allclose(rgb, want, rtol=1e-6, atol=1e-7)
+    assert np.array_equal(O.tonemap(a, 40, 2), O.tonemap(a, 30, 2))
