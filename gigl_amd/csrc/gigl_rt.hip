@@ -629,30 +629,42 @@ __global__ void __launch_bounds__(256) primary_rays_kernel(const Cam12 cam, unsi
 
 // ---- fog: sampleDensity and the GLSL ray march ----------------------------------------------
 struct FogParams {
-    const unsigned char* dens;
+    // Corner bricks: brick (bx,by,bz), bx in [0,rx], holds the 8 texels (x,y,z) with x in
+    // {bx-1, bx}, ... as bytes, byte index = dx + 2*dy + 4*dz, texels outside the volume 0
+    // (DensityField::sample, DensityField.cpp:204-211).  One 8-byte load per trilinear sample.
+    const uint2* bricks;
     int rx, ry, rz;
     float mnx, mny, mnz, mxx, mxy, mxz;
     float ext_k;
     int n_intervals;
 };
 
-__device__ __forceinline__ float fog_texel(const FogParams& F, int x, int y, int z) {  // DensityField.cpp:204-211
-    if (x >= 0 && x < F.rx && y >= 0 && y < F.ry && z >= 0 && z < F.rz)
-        return (float)F.dens[x + y * F.rx + z * F.rx * F.ry] / 255.0f;
-    return 0.0f;
+// b / 255.0f (DensityField.cpp:210) without the divide: one Newton correction of b * (1/255) gives
+// the correctly rounded quotient for every byte value (checked exhaustively,
+// tests/test_host_logic.py::test_byte_unorm_is_exact_division).
+__device__ __forceinline__ float byte_unorm(unsigned b) {
+    const float rcp = 1.0f / 255.0f, fb = (float)b;
+    const float r = fb * rcp;
+    return __builtin_fmaf(__builtin_fmaf(-255.0f, r, fb), rcp, r);
 }
 __device__ __forceinline__ float lerp1(float p0, float p1, float t) { return (1.0f - t) * p0 + t * p1; }
 // DensityField.cpp:180-201 from a normalized position; lerp order x, y, z (Interpolation.hpp:8-23)
 __device__ __forceinline__ float fog_filter(const FogParams& F, float nx, float ny, float nz) {
     const float tcx = nx * (float)F.rx - 0.5f, tcy = ny * (float)F.ry - 0.5f, tcz = nz * (float)F.rz - 0.5f;
     const float fx = floorf(tcx), fy = floorf(tcy), fz = floorf(tcz);
-    const int x0 = (int)fx, x1 = (int)ceilf(tcx), y0 = (int)fy, y1 = (int)ceilf(tcy), z0 = (int)fz,
-              z1 = (int)ceilf(tcz);
+    const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
     const float tx = tcx - (float)x0, ty = tcy - (float)y0, tz = tcz - (float)z0;
-    const float d000 = fog_texel(F, x0, y0, z0), d100 = fog_texel(F, x1, y0, z0);
-    const float d010 = fog_texel(F, x0, y1, z0), d110 = fog_texel(F, x1, y1, z0);
-    const float d001 = fog_texel(F, x0, y0, z1), d101 = fog_texel(F, x1, y0, z1);
-    const float d011 = fog_texel(F, x0, y1, z1), d111 = fog_texel(F, x1, y1, z1);
+    // The reference's upper texel is ceil(tc), which equals x0 when tc is an integer; the brick's
+    // is x0 + 1.  They differ only when the weight t is exactly 0, where (1-0)*a + 0*b = a for
+    // either b, so the filtered value is the same bit for bit.
+    const unsigned bx = (unsigned)x0 + 1u, by = (unsigned)y0 + 1u, bz = (unsigned)z0 + 1u;
+    uint2 w = make_uint2(0u, 0u);   // every texel outside: the lerps still run (inf/NaN weights propagate)
+    if (bx <= (unsigned)F.rx && by <= (unsigned)F.ry && bz <= (unsigned)F.rz)
+        w = F.bricks[bx + (size_t)by * (unsigned)(F.rx + 1) + (size_t)bz * (unsigned)(F.rx + 1) * (unsigned)(F.ry + 1)];
+    const float d000 = byte_unorm(w.x & 0xFFu), d100 = byte_unorm((w.x >> 8) & 0xFFu);
+    const float d010 = byte_unorm((w.x >> 16) & 0xFFu), d110 = byte_unorm(w.x >> 24);
+    const float d001 = byte_unorm(w.y & 0xFFu), d101 = byte_unorm((w.y >> 8) & 0xFFu);
+    const float d011 = byte_unorm((w.y >> 16) & 0xFFu), d111 = byte_unorm(w.y >> 24);
     const float i0 = lerp1(lerp1(d000, d100, tx), lerp1(d010, d110, tx), ty);
     const float i1 = lerp1(lerp1(d001, d101, tx), lerp1(d011, d111, tx), ty);
     return lerp1(i0, i1, tz);
@@ -1013,7 +1025,7 @@ struct gigl_scene {
 
 struct gigl_fog {
     int device = 0;
-    unsigned char* d_dens = nullptr;
+    uint2* d_bricks = nullptr;
     FogParams fp;
 };
 
@@ -1748,15 +1760,29 @@ int gigl_fog_create(const uint8_t* dens, const int res[3], const float box[6], f
     DeviceGuard g(device);
     gigl_fog* f = new gigl_fog();
     f->device = device;
-    const size_t nb = (size_t)res[0] * res[1] * res[2];
-    hipError_t e = hipMalloc((void**)&f->d_dens, nb);
-    if (e == hipSuccess) e = hipMemcpy(f->d_dens, dens, nb, hipMemcpyHostToDevice);
+    // corner bricks, see FogParams
+    const int rx = res[0], ry = res[1], rz = res[2];
+    std::vector<uint64_t> bricks((size_t)(rx + 1) * (ry + 1) * (rz + 1));
+    auto texel = [&](int x, int y, int z) -> uint64_t {
+        if (x < 0 || x >= rx || y < 0 || y >= ry || z < 0 || z >= rz) return 0;
+        return dens[x + (size_t)y * rx + (size_t)z * rx * ry];
+    };
+    for (int bz = 0; bz <= rz; ++bz)
+        for (int by = 0; by <= ry; ++by)
+            for (int bx = 0; bx <= rx; ++bx) {
+                uint64_t w = 0;
+                for (int c = 0; c < 8; ++c) w |= texel(bx - 1 + (c & 1), by - 1 + ((c >> 1) & 1), bz - 1 + (c >> 2)) << (8 * c);
+                bricks[bx + (size_t)by * (rx + 1) + (size_t)bz * (rx + 1) * (ry + 1)] = w;
+            }
+    const size_t nb = bricks.size() * 8;
+    hipError_t e = hipMalloc((void**)&f->d_bricks, nb);
+    if (e == hipSuccess) e = hipMemcpy(f->d_bricks, bricks.data(), nb, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
-        if (f->d_dens) (void)hipFree(f->d_dens);
+        if (f->d_bricks) (void)hipFree(f->d_bricks);
         delete f;
         return fail(GIGL_ERR_HIP, std::string("fog upload: ") + hipGetErrorString(e));
     }
-    f->fp = FogParams{f->d_dens, res[0], res[1], res[2], box[0], box[1], box[2], box[3], box[4], box[5], ext_k,
+    f->fp = FogParams{f->d_bricks, res[0], res[1], res[2], box[0], box[1], box[2], box[3], box[4], box[5], ext_k,
                       n_intervals};
     *out = f;
     return GIGL_OK;
@@ -1766,7 +1792,7 @@ int gigl_fog_destroy(gigl_fog* f) {
     if (!f) return GIGL_OK;
     DeviceGuard g(f->device);
     (void)hipDeviceSynchronize();
-    (void)hipFree(f->d_dens);
+    (void)hipFree(f->d_bricks);
     delete f;
     return GIGL_OK;
 }

@@ -154,3 +154,36 @@ def test_shard_ranges():
     assert shard.chunk_bounds(10, 4) == [0, 2, 5, 7, 10]
     with pytest.raises(ValueError):
         shard.shard_range(5, 2, 2)
+
+
+def _round_f32(x):
+    """Fraction -> nearest binary32 (ties to even), for normal-range values; returns a Fraction."""
+    from fractions import Fraction
+    if x == 0:
+        return Fraction(0)
+    s, a, e = (-1 if x < 0 else 1), abs(x), 0
+    while a >= (1 << 24):
+        a, e = a / 2, e + 1
+    while a < (1 << 23):
+        a, e = a * 2, e - 1
+    assert e >= -149
+    m = a.numerator // a.denominator
+    rem = a - m
+    if rem > Fraction(1, 2) or (rem == Fraction(1, 2) and (m & 1)):
+        m += 1
+    return s * Fraction(m) * (Fraction(2) ** e)
+
+
+def test_byte_unorm_is_exact_division():
+    """The fog kernels turn a density byte into b / 255.0f (DensityField.cpp:210) with one multiply
+    and two fused multiply-adds (byte_unorm in gigl_rt.hip); every byte value must give the
+    correctly rounded quotient, evaluated here in exact rational arithmetic."""
+    from fractions import Fraction
+    rcp = _round_f32(Fraction(1, 255))
+    assert float(rcp) == float(np.float32(1.0) / np.float32(255.0))
+    for b in range(256):
+        fb = Fraction(b)
+        r = _round_f32(fb * rcp)
+        e = _round_f32(Fraction(-255) * r + fb)        # fmaf(-255, r, b)
+        q = _round_f32(e * rcp + r)                     # fmaf(e, rcp, r)
+        assert float(q) == float(np.float32(b) / np.float32(255.0)), b
