@@ -8,7 +8,7 @@ A "step" is one closest-hit pass over the whole ray batch, rays and tree residen
 
 N > 1 (one process per GPU, launched by torch.distributed.run): the tree is replicated, every
 rank traces its own 2^24-ray shard (weak scaling: N=8 is configs[3]'s 128M rays) and the 16-byte
-hit records are gathered to rank 0 over RCCL, pipelined in chunks behind the traversal.
+hit records are gathered to rank 0 over RCCL behind the next step's traversal (two hit buffers).
 
 Prints ONE JSON line on rank 0.
 """
@@ -34,7 +34,6 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--tess", type=int, default=158, help="k of scene S(k); 158 -> 998,560 triangles")
     ap.add_argument("--rays-log2", type=int, default=24, help="rays per GPU = 2^this")
-    ap.add_argument("--chunks", type=int, default=4, help="gather pipeline depth for N > 1")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the RCCL gather of hit records")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--extras", action="store_true", help="also time any-hit and the Cornell configs (N=1)")
@@ -81,41 +80,48 @@ def main():
     stream = torch.cuda.current_stream()
     sh = stream.cuda_stream
 
+    # N > 1: step i's 16-byte hit records go to rank 0 on a second stream while step i+1 traverses
+    # (two hit buffers).  Every timed step's gather completes inside the timed region; only the last
+    # one is exposed.  One traversal launch per step: splitting a step into chunks to pipeline inside
+    # it costs ~0.7 ms of drain per extra launch of the persistent kernel.
     gather = world > 1 and not args.no_gather
-    chunks = max(1, args.chunks) if gather else 1
-    bounds = [(i * n) // chunks for i in range(chunks + 1)]
     comm_stream = torch.cuda.Stream(device=device) if gather else None
+    hit_bufs = [d_hits, torch.empty_like(d_hits)] if gather else [d_hits]
     gathered = None
     if gather and rank == 0:
         gathered = [torch.empty((n, 4), dtype=torch.int32, device=device) for _ in range(world)]
     host_gather = gather and backend != "nccl"
+    pending = {}
+    step_no = [0]
 
     def step():
+        i = step_no[0]
+        step_no[0] += 1
+        buf = hit_bufs[i % len(hit_bufs)]
+        if gather and (i - 2) in pending:
+            pending.pop(i - 2).wait()      # the gather that last read this buffer (stream-level wait)
+        scene.trace_closest_device(d_o.data_ptr(), d_d.data_ptr(), n, buf.data_ptr(), sh)
         if not gather:
-            scene.trace_closest_device(d_o.data_ptr(), d_d.data_ptr(), n, d_hits.data_ptr(), sh)
             return
-        works = []
-        for c in range(chunks):
-            lo, hi = bounds[c], bounds[c + 1]
-            scene.trace_closest_device(d_o[lo:hi].data_ptr(), d_d[lo:hi].data_ptr(), hi - lo,
-                                       d_hits[lo:hi].data_ptr(), sh)
-            ev = torch.cuda.Event()
-            ev.record(stream)
-            with torch.cuda.stream(comm_stream):
-                comm_stream.wait_event(ev)
-                src = d_hits[lo:hi]
-                if host_gather:   # rehearsal backend (gloo): through host memory
-                    src_h = src.cpu()
-                    dst = [torch.empty_like(src_h) for _ in range(world)] if rank == 0 else None
-                    dist.gather(src_h, dst, dst=0)
-                else:
-                    dst = [g[lo:hi] for g in gathered] if rank == 0 else None
-                    works.append(dist.gather(src, dst, dst=0, async_op=True))
-        for w in works:
-            w.wait()
-        stream.wait_stream(comm_stream)
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        with torch.cuda.stream(comm_stream):
+            comm_stream.wait_event(ev)
+            if host_gather:   # rehearsal backend (gloo): through host memory, synchronous
+                src_h = buf.cpu()
+                dst = [torch.empty_like(src_h) for _ in range(world)] if rank == 0 else None
+                dist.gather(src_h, dst, dst=0)
+            else:
+                pending[i] = dist.gather(buf, gathered if rank == 0 else None, dst=0, async_op=True)
+
+    def drain():
+        for k in sorted(pending):
+            pending.pop(k).wait()
+        if gather:
+            stream.wait_stream(comm_stream)
 
     def barrier():
+        drain()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -143,7 +149,7 @@ def main():
 
     out = None
     if rank == 0:
-        hits = d_hits.cpu().numpy().view(rt.HIT_DTYPE).reshape(-1)
+        hits = hit_bufs[(step_no[0] - 1) % len(hit_bufs)].cpu().numpy().view(rt.HIT_DTYPE).reshape(-1)
         # size-independent sanity at full size: every reported hit lies inside its ray's range
         hit_mask = hits["tri_id"] != rt.GIGL_MISS
         assert (hits["tri_id"][hit_mask] < len(T)).all() and (hits["t"][hit_mask] > 0).all()
@@ -199,7 +205,7 @@ def main():
             "config": {"workload": "S(%d) tessellated Cornell scene, %d triangles, k-d tree %d nodes depth %d; "
                                    "2^%d incoherent diffuse-bounce closest-hit rays per GPU%s"
                                    % (args.tess, len(T), st.n_nodes, st.actual_depth, args.rays_log2,
-                                      ("; hit records gathered to rank 0 over %s in %d chunks" % (backend, chunks))
+                                      ("; hit records gathered to rank 0 over %s behind the next step's traversal" % backend)
                                       if gather else ""),
                        "triangles": int(len(T)), "rays_per_gpu": int(n), "tree_build_ms": round(st.build_ms, 1),
                        "tree_device_bytes": int(st.device_bytes), "setup_s": round(setup_s, 1)},
