@@ -146,6 +146,8 @@ struct TraceParams {
     const uint4* prim_hits;
     const float* lights;
     unsigned n_lights;
+    // GEN 3: (point, light) pairs from explicit points (x, y, z, valid)
+    const float4* points;
     // outputs
     uint4* hits;
     unsigned long long* bits;
@@ -229,12 +231,25 @@ __device__ __forceinline__ bool fetch_ray(const TraceParams& P, unsigned idx, Ra
         set_dir(r, dx, dy, dz);
         r.tmin = 0.0f; r.tmax = FLT_MAX;
         return true;
-    } else {
+    } else if (GEN == 2) {
         ShadowSeg s;
         if (!shadow_segment(P, idx, s)) return false;
         r.ox = s.px + kRayOffset * s.nx; r.oy = s.py + kRayOffset * s.ny; r.oz = s.pz + kRayOffset * s.nz;
         set_dir(r, s.wx, s.wy, s.wz);
         r.tmin = 0.0f; r.tmax = s.dist;
+        return true;
+    } else {
+        // visibility of light l from a point in the volume: Ray{p, normalize(L - p)} (no normal,
+        // so no origin offset), range (0, |L - p|)
+        const unsigned pt = idx / P.n_lights, l = idx - pt * P.n_lights;
+        const float4 p = P.points[pt];
+        if (!(p.w > 0.0f)) return false;
+        const float vx = P.lights[3 * l] - p.x, vy = P.lights[3 * l + 1] - p.y, vz = P.lights[3 * l + 2] - p.z;
+        const float dist_sq = (vx * vx + vy * vy) + vz * vz;
+        const float iv = 1.0f / sqrtf(dist_sq);
+        r.ox = p.x; r.oy = p.y; r.oz = p.z;
+        set_dir(r, vx * iv, vy * iv, vz * iv);
+        r.tmin = 0.0f; r.tmax = sqrtf(dist_sq);
         return true;
     }
 }
@@ -962,6 +977,146 @@ __global__ void __launch_bounds__(256) shade_surface_kernel(FogParams F, ShadePa
         }
         S.accum[pt] = make_float4(col.x, col.y, col.z, 1.0f);                          // :339
         if (S.fog_dist && F.ext_k > 0.0f) S.fog_dist[pt] = make_float2(f_min, f_max);  // recordRayDist, :314
+    }
+}
+
+// ---- Volume.frag (Source/Shaders/Volume.frag:268-314): half-resolution in-scattering ----------
+struct VolumeParams {
+    float cam[3];
+    unsigned res_x, res_y;            // full resolution (CAM_RES of Surface.frag); this pass runs at res/2
+    unsigned n_samples;               // gi_enabled ? MAX_VOL_SAMP / 4 : MAX_VOL_SAMP
+    unsigned n_ppls, n_vpls;
+    int gi_enabled, clamp_rsq, transm_opt, frame_id, pi_res_z;
+    float sca_k, sca_albedo;
+    const float4* prim_o;             // full-resolution primary rays and hits (the G-buffer stand-in)
+    const float4* prim_d;
+    const uint4* hits;
+    const float2* fog_dist;           // full resolution, written by shade_surface_kernel
+    const float* rnd_offsets;         // res/2 x res/2
+    const float* halton;              // MAX_FRAMES * MAX_VOL_SAMP values
+    const float* pi_dens;
+    const float* ppls;
+    const float* vpls;
+    const unsigned long long* bits;   // pair = (pixel * n_samples + sample) * n_lights + light
+    float4* points;                   // volume_samples_kernel: (s_pos, valid)
+    float4* vol_comp;                 // shade_volume_kernel: rgb, 1
+};
+
+struct VolSample { F3 pos; float transm; bool valid; };
+struct VolPixel { F3 ray_d; float t_min, t_max, z_offset; unsigned tx, ty; bool fog; };
+
+// per-pixel part of main(), Volume.frag:272-282
+__device__ __forceinline__ VolPixel volume_pixel(const VolumeParams& V, unsigned hx, unsigned hy) {
+    VolPixel px;
+    const size_t full = (size_t)(2u * hx + 1u) + (size_t)(2u * hy + 1u) * V.res_x;   // texel (2x+1, 2y+1), :90, :95
+    const float2 fd = V.fog_dist[full];
+    px.t_min = fd.x; px.t_max = fd.y;
+    px.fog = px.t_max > 0.0f && V.frame_id < 30;
+    px.ray_d = f3(0.0f, 0.0f, 0.0f);
+    px.z_offset = 0.0f;
+    // gl_FragCoord.xy / CAM_RES with `#define CAM_RES 1024 / 2` is (xy / 1024) / 2 (Volume.frag:4,
+    // :285): the lookup lands in the lower-left quarter of pi_dens, nearest texel = (hx/2, hy/2)
+    px.tx = hx >> 1; px.ty = hy >> 1;
+    if (px.fog) {
+        const float4 o4 = V.prim_o[full], d4 = V.prim_d[full];
+        const uint4 h = V.hits[full];
+        const F3 w_pos = f3(o4.x, o4.y, o4.z) + __uint_as_float(h.y) * f3(d4.x, d4.y, d4.z);
+        px.ray_d = norm3(w_pos - f3(V.cam[0], V.cam[1], V.cam[2]));
+        px.z_offset = V.rnd_offsets[hx + (size_t)hy * (V.res_x / 2u)];
+    }
+    return px;
+}
+// per-sample part, Volume.frag:285-291
+__device__ __forceinline__ VolSample volume_sample(const FogParams& F, const VolumeParams& V, const VolPixel& px,
+                                                  unsigned s) {
+    VolSample smp;
+    const float hz = V.halton[s + V.n_samples * (unsigned)V.frame_id] + px.z_offset;
+    const float z = smin(smax(hz, 0.0f), 0.995f);                                  // clamp
+    const float t = px.t_min + z * (px.t_max - px.t_min);
+    smp.pos = f3(V.cam[0], V.cam[1], V.cam[2]) + t * px.ray_d;
+    float tz = z * (float)V.pi_res_z - 0.5f;
+    tz = smin(smax(tz, 0.0f), (float)(V.pi_res_z - 1));
+    const float fz = floorf(tz);
+    const int z0 = (int)fz, z1 = z0 + 1 < V.pi_res_z ? z0 + 1 : V.pi_res_z - 1;
+    const float f = tz - fz;
+    const size_t plane = (size_t)V.res_x * V.res_y, at = px.tx + (size_t)px.ty * V.res_x;
+    const float a = V.pi_dens[at + (size_t)z0 * plane], b = V.pi_dens[at + (size_t)z1 * plane];
+    smp.transm = expf(-(F.ext_k * ((1.0f - f) * a + f * b)));
+    smp.valid = smp.transm > 0.001f;                                               // :292
+    return smp;
+}
+
+__global__ void __launch_bounds__(256) volume_samples_kernel(FogParams F, VolumeParams V) {
+    const unsigned hw = V.res_x / 2u, n_pix = hw * (V.res_y / 2u);
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n_pix * V.n_samples; i += gridDim.x * 256u) {
+        const unsigned pix = i / V.n_samples, s = i - pix * V.n_samples;
+        const VolPixel px = volume_pixel(V, pix % hw, pix / hw);
+        float4 out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (px.fog) {
+            const VolSample smp = volume_sample(F, V, px, s);
+            if (smp.valid) out = make_float4(smp.pos.x, smp.pos.y, smp.pos.z, 1.0f);
+        }
+        V.points[i] = out;
+    }
+}
+
+// calcTransm of Volume.frag:159-181 (transm_opt: constant medium at the sample point's density)
+__device__ __forceinline__ float calc_transm_vol(const FogParams& F, F3 p, float density, F3 w, float dist_sq,
+                                                 int transm_opt) {
+    if (!transm_opt) return calc_transm(F, p.x, p.y, p.z, w.x, w.y, w.z, dist_sq);
+    if (!(F.ext_k > 0.0f)) return 1.0f;
+    const float max_dist = sqrtf(dist_sq);
+    const float ivx = 1.0f / w.x, ivy = 1.0f / w.y, ivz = 1.0f / w.z;
+    float t0 = (F.mnx - p.x) * ivx, t1 = (F.mxx - p.x) * ivx;
+    float t_min = smin(t0, t1), t_max = smax(t0, t1);
+    t0 = (F.mny - p.y) * ivy; t1 = (F.mxy - p.y) * ivy;
+    t_min = smax(t_min, smin(t0, t1)); t_max = smin(t_max, smax(t0, t1));
+    t0 = (F.mnz - p.z) * ivz; t1 = (F.mxz - p.z) * ivz;
+    t_min = smax(t_min, smin(t0, t1)); t_max = smin(t_max, smax(t0, t1));
+    if (!(t_max > smax(t_min, 0.0f) && t_min < max_dist)) return 1.0f;
+    t_min = smax(t_min, 0.0f);
+    t_max = smin(t_max, max_dist);
+    return expf(-(F.ext_k * density * (t_max - t_min)));
+}
+
+// One half-resolution pixel per lane; samples and lights in the shader's order.
+__global__ void __launch_bounds__(256) shade_volume_kernel(FogParams F, VolumeParams V) {
+    const unsigned hw = V.res_x / 2u, n_pix = hw * (V.res_y / 2u);
+    const unsigned n_lights = V.n_ppls + V.n_vpls;
+    const float idx = 1.0f / (F.mxx - F.mnx), idy = 1.0f / (F.mxy - F.mny), idz = 1.0f / (F.mxz - F.mnz);
+    for (unsigned pix = blockIdx.x * 256u + threadIdx.x; pix < n_pix; pix += gridDim.x * 256u) {
+        const VolPixel px = volume_pixel(V, pix % hw, pix / hw);
+        F3 col = f3(0.0f, 0.0f, 0.0f);
+        if (px.fog) {
+            const F3 O = -px.ray_d;
+            for (unsigned s = 0; s < V.n_samples; ++s) {
+                const VolSample smp = volume_sample(F, V, px, s);
+                if (!smp.valid) continue;
+                // calcFogDens, Volume.frag:121-126
+                const float density = fog_filter(F, (smp.pos.x - F.mnx) * idx, (smp.pos.y - F.mny) * idy,
+                                                 (smp.pos.z - F.mnz) * idz);
+                for (unsigned l = 0; l < n_lights; ++l) {
+                    const bool is_ppl = l < V.n_ppls;
+                    if (is_ppl ? !V.clamp_rsq : !V.gi_enabled) continue;                  // :293, :299
+                    const size_t pair = ((size_t)pix * V.n_samples + s) * n_lights + l;
+                    if ((V.bits[pair >> 6] >> (pair & 63u)) & 1ull) continue;             // visibility > 0.0
+                    const float* v = V.vpls + 24 * (size_t)(is_ppl ? 0u : l - V.n_ppls);
+                    const F3 L = is_ppl ? ld3(V.ppls + 8 * l) : ld3(v);
+                    const F3 dd = smp.pos - L;
+                    const float dist_sq = dot3(dd, dd);
+                    const F3 I = norm3(-dd);
+                    const float tr = calc_transm_vol(F, smp.pos, density, I, dist_sq, V.transm_opt);
+                    F3 Li;
+                    if (is_ppl) Li = (tr * ld3(V.ppls + 8 * l + 4)) * (1.0f / dist_sq);                 // :235-236
+                    else Li = (tr * compute_le(v, -I, V.sca_albedo)) * (1.0f / smax(dist_sq, 75.0f * 75.0f));  // :258-259
+                    const float cos_the = -dot3(I, O);
+                    const F3 c = ((phase_hg(cos_the) * V.sca_k) * density) * Li;                        // :239, :262
+                    col = col + smp.transm * c;                                                          // :296, :302
+                }
+            }
+            col = col * ((px.t_max - px.t_min) / (float)V.n_samples);                                    // :308-309
+        }
+        V.vol_comp[pix] = make_float4(col.x, col.y, col.z, 1.0f);
     }
 }
 
@@ -1753,6 +1908,89 @@ int gigl_shade_surface_device(const gigl_scene* s, const gigl_fog* fog, const gi
     S.bits = (const unsigned long long*)occluded_bits; S.transm = transm; S.pi_dens = pi_dens;
     S.accum = (float4*)accum_rgba; S.fog_dist = (float2*)fog_dist;
     hipLaunchKernelGGL(shade_surface_kernel, dim3((unsigned)((n_pts + 255) / 256)), dim3(256), 0, (hipStream_t)stream, F, S);
+    HIP_TRY(hipGetLastError());
+    return GIGL_OK;
+}
+
+namespace {
+int volume_params(const gigl_scene* s, const gigl_fog* fog, const gigl_shade_params* prm, VolumeParams& V) {
+    if (!s || !fog || !prm) return fail(GIGL_ERR_INVALID, "scene, fog or params is NULL");
+    if (s->device == GIGL_DEVICE_NONE) return fail(GIGL_ERR_NO_DEVICE, "host-only scene: no device to shade on");
+    if (fog->device != s->device) return fail(GIGL_ERR_INVALID, "fog and scene live on different devices");
+    if (prm->res_x < 2 || prm->res_y < 2 || (prm->res_x & 1) || (prm->res_y & 1))
+        return fail(GIGL_ERR_INVALID, "the volume pass needs an even resolution");
+    if ((uint64_t)prm->res_x * (uint64_t)prm->res_y > (1ull << 28)) return fail(GIGL_ERR_TOO_LARGE, "at most 2^28 pixels");
+    if (prm->n_ppls < 0 || prm->n_vpls < 0 || prm->pi_res_z <= 0) return fail(GIGL_ERR_INVALID, "bad light count or pi_res_z");
+    if (prm->frame_id < 0) return fail(GIGL_ERR_INVALID, "negative frame_id");
+    V = VolumeParams{};
+    for (int a = 0; a < 3; ++a) V.cam[a] = prm->cam_pos[a];
+    V.res_x = (unsigned)prm->res_x; V.res_y = (unsigned)prm->res_y;
+    V.n_samples = prm->gi_enabled ? 8u : 32u;       // MAX_VOL_SAMP / 4 : MAX_VOL_SAMP, Volume.frag:277
+    V.n_ppls = (unsigned)prm->n_ppls; V.n_vpls = (unsigned)prm->n_vpls;
+    V.gi_enabled = prm->gi_enabled; V.clamp_rsq = prm->clamp_rsq; V.transm_opt = prm->transm_opt;
+    V.frame_id = prm->frame_id; V.pi_res_z = prm->pi_res_z; V.sca_k = prm->sca_k; V.sca_albedo = prm->sca_albedo;
+    return GIGL_OK;
+}
+}  // namespace
+
+int gigl_volume_samples_device(const gigl_scene* s, const gigl_fog* fog, const gigl_shade_params* prm,
+                               const void* prim_o_tmin, const void* prim_d_tmax, const gigl_hit* prim_hits,
+                               const float* fog_dist, const float* rnd_offsets, const float* halton,
+                               const float* pi_dens, float* points, void* stream) {
+    VolumeParams V;
+    int rc = volume_params(s, fog, prm, V);
+    if (rc != GIGL_OK) return rc;
+    if (!prim_o_tmin || !prim_d_tmax || !prim_hits || !fog_dist || !rnd_offsets || !halton || !pi_dens || !points)
+        return fail(GIGL_ERR_INVALID, "NULL pointer");
+    DeviceGuard g(s->device);
+    V.prim_o = (const float4*)prim_o_tmin; V.prim_d = (const float4*)prim_d_tmax; V.hits = (const uint4*)prim_hits;
+    V.fog_dist = (const float2*)fog_dist; V.rnd_offsets = rnd_offsets; V.halton = halton; V.pi_dens = pi_dens;
+    V.points = (float4*)points;
+    const uint64_t n = (uint64_t)(V.res_x / 2) * (V.res_y / 2) * V.n_samples;
+    hipLaunchKernelGGL(volume_samples_kernel, dim3(stream_grid(s, n)), dim3(256), 0, (hipStream_t)stream, fog->fp, V);
+    HIP_TRY(hipGetLastError());
+    return GIGL_OK;
+}
+
+int gigl_shadow_points_device(const gigl_scene* s, const float* points, uint64_t n_pts, const float* lights,
+                              uint32_t n_lights, uint64_t* occluded_bits, void* stream) {
+    if (!s) return fail(GIGL_ERR_INVALID, "scene is NULL");
+    if (s->device == GIGL_DEVICE_NONE) return fail(GIGL_ERR_NO_DEVICE, "host-only scene: no device to trace on");
+    const uint64_t n = n_pts * (uint64_t)n_lights;
+    if (n == 0) return GIGL_OK;
+    if (!points || !lights || !occluded_bits) return fail(GIGL_ERR_INVALID, "NULL pointer");
+    if (n > kMaxRays) return fail(GIGL_ERR_TOO_LARGE, "n_pts * n_lights must stay below 0xF0000000");
+    DeviceGuard g(s->device);
+    TraceParams P = {};
+    P.n = (unsigned)n;
+    P.points = (const float4*)points;
+    P.lights = lights;
+    P.n_lights = n_lights;
+    P.bits = (unsigned long long*)occluded_bits;
+    return launch_trace<true, 3>(s, P, (hipStream_t)stream);
+}
+
+int gigl_shade_volume_device(const gigl_scene* s, const gigl_fog* fog, const gigl_shade_params* prm,
+                             const void* prim_o_tmin, const void* prim_d_tmax, const gigl_hit* prim_hits,
+                             const float* fog_dist, const float* rnd_offsets, const float* halton,
+                             const float* pi_dens, const float* ppls, const void* vpls,
+                             const uint64_t* occluded_bits, float* vol_comp_rgba, void* stream) {
+    VolumeParams V;
+    int rc = volume_params(s, fog, prm, V);
+    if (rc != GIGL_OK) return rc;
+    if (!prim_o_tmin || !prim_d_tmax || !prim_hits || !fog_dist || !rnd_offsets || !halton || !pi_dens || !vol_comp_rgba)
+        return fail(GIGL_ERR_INVALID, "NULL pointer");
+    if ((V.n_ppls + V.n_vpls) > 0 && !occluded_bits) return fail(GIGL_ERR_INVALID, "lights given without occlusion bits");
+    if ((V.n_ppls > 0 && !ppls) || (V.n_vpls > 0 && !vpls)) return fail(GIGL_ERR_INVALID, "NULL light array");
+    const uint64_t n_pix = (uint64_t)(V.res_x / 2) * (V.res_y / 2);
+    if (n_pix * V.n_samples * (uint64_t)(V.n_ppls + V.n_vpls ? V.n_ppls + V.n_vpls : 1) > kMaxRays)
+        return fail(GIGL_ERR_TOO_LARGE, "pixels * samples * lights must stay below 0xF0000000");
+    DeviceGuard g(s->device);
+    V.prim_o = (const float4*)prim_o_tmin; V.prim_d = (const float4*)prim_d_tmax; V.hits = (const uint4*)prim_hits;
+    V.fog_dist = (const float2*)fog_dist; V.rnd_offsets = rnd_offsets; V.halton = halton; V.pi_dens = pi_dens;
+    V.ppls = ppls; V.vpls = (const float*)vpls; V.bits = (const unsigned long long*)occluded_bits;
+    V.vol_comp = (float4*)vol_comp_rgba;
+    hipLaunchKernelGGL(shade_volume_kernel, dim3(stream_grid(s, n_pix)), dim3(256), 0, (hipStream_t)stream, fog->fp, V);
     HIP_TRY(hipGetLastError());
     return GIGL_OK;
 }

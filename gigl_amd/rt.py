@@ -25,7 +25,7 @@ SYMBOLS = [
     "gigl_gen_primary_rays_device", "gigl_trace_primary_device", "gigl_shadow_batch_device", "gigl_fog_create",
     "gigl_fog_destroy", "gigl_transmittance_device", "gigl_sample_density", "gigl_debug_rescaled_eps",
     "gigl_set_option", "gigl_debug_last_stats", "gigl_compute_pi_density_device", "gigl_shade_surface_device",
-    "gigl_tonemap_device",
+    "gigl_tonemap_device", "gigl_volume_samples_device", "gigl_shadow_points_device", "gigl_shade_volume_device",
 ]
 
 
@@ -39,7 +39,8 @@ class ShadeParams(C.Structure):
     """gigl_shade_params (include/gigl_rt.h)."""
     _fields_ = [("cam_pos", C.c_float * 3), ("res_x", C.c_int), ("res_y", C.c_int), ("first", C.c_uint64),
                 ("n_ppls", C.c_int), ("n_vpls", C.c_int), ("gi_enabled", C.c_int), ("clamp_rsq", C.c_int),
-                ("frame_id", C.c_int), ("pi_res_z", C.c_int), ("sca_albedo", C.c_float)]
+                ("frame_id", C.c_int), ("pi_res_z", C.c_int), ("sca_albedo", C.c_float),
+                ("transm_opt", C.c_int), ("sca_k", C.c_float)]
 
 
 class TreeStats(C.Structure):
@@ -92,6 +93,9 @@ def lib():
         L.gigl_compute_pi_density_device.argtypes = [vp, vp, vp, i, i, vp, vp]
         L.gigl_shade_surface_device.argtypes = [vp, vp, vp, vp, vp, vp, u64, vp, u32, vp, vp, vp, vp, vp, vp, vp, vp]
         L.gigl_tonemap_device.argtypes = [i, vp, u64, i, i, vp, vp]
+        L.gigl_volume_samples_device.argtypes = [vp] * 12
+        L.gigl_shadow_points_device.argtypes = [vp, vp, u64, vp, u32, vp, vp]
+        L.gigl_shade_volume_device.argtypes = [vp] * 15
         for s in SYMBOLS:
             if s != "gigl_last_error":
                 getattr(L, s).restype = C.c_int
@@ -249,6 +253,21 @@ class Scene:
                                                d_ptr, hits_ptr, n_pts, materials_ptr, n_materials, ppls_ptr,
                                                vpls_ptr, bits_ptr, transm_ptr, pi_dens_ptr, accum_ptr,
                                                fog_dist_ptr, stream))
+
+    # Volume.frag main() in three steps (Source/Shaders/Volume.frag:268-314), see include/gigl_rt.h
+    def volume_samples_device(self, fog, prm, o_ptr, d_ptr, hits_ptr, fog_dist_ptr, rnd_ptr, halton_ptr, pi_dens_ptr,
+                              points_ptr, stream=0):
+        _check(lib().gigl_volume_samples_device(self.h, fog.h, C.byref(prm), o_ptr, d_ptr, hits_ptr, fog_dist_ptr,
+                                                rnd_ptr, halton_ptr, pi_dens_ptr, points_ptr, stream))
+
+    def shadow_points_device(self, points_ptr, n_pts, lights_ptr, n_lights, bits_ptr, stream=0):
+        _check(lib().gigl_shadow_points_device(self.h, points_ptr, n_pts, lights_ptr, n_lights, bits_ptr, stream))
+
+    def shade_volume_device(self, fog, prm, o_ptr, d_ptr, hits_ptr, fog_dist_ptr, rnd_ptr, halton_ptr, pi_dens_ptr,
+                            ppls_ptr, vpls_ptr, bits_ptr, vol_comp_ptr, stream=0):
+        _check(lib().gigl_shade_volume_device(self.h, fog.h, C.byref(prm), o_ptr, d_ptr, hits_ptr, fog_dist_ptr,
+                                              rnd_ptr, halton_ptr, pi_dens_ptr, ppls_ptr, vpls_ptr, bits_ptr,
+                                              vol_comp_ptr, stream))
 
     def shadow_batch_device(self, o_ptr, d_ptr, hits_ptr, n_pts, lights_ptr, n_lights, bits_ptr, fog=None,
                             transm_ptr=None, stream=0):

@@ -152,6 +152,9 @@ typedef struct gigl_shade_params {
     int      gi_enabled, clamp_rsq, frame_id;
     int      pi_res_z;
     float    sca_albedo;      /* FogVolume::getScaAlbedo, Source/Fog/FogVolume.cpp:44-46 */
+    /* volume pass only (Volume.frag uniforms) */
+    int      transm_opt;      /* shadow segments: 1 = constant medium at the sample, 0 = ray march */
+    float    sca_k;           /* scattering coefficient per unit density */
 } gigl_shade_params;
 /* materials: float[12*n_materials] = k_d, pad, k_s, n_s, k_e, pad (Source/RT/RTBase.h:72-77).
  * ppls: float[8*n_ppls] = w_pos, pad, intens, pad (std140 PrimaryPointLight).
@@ -165,6 +168,30 @@ int gigl_shade_surface_device(const gigl_scene* s, const gigl_fog* fog, const gi
                               uint64_t n_pts, const float* materials, uint32_t n_materials, const float* ppls,
                               const void* vpls, const uint64_t* occluded_bits, const float* transm,
                               const float* pi_dens, float* accum_rgba, float* fog_dist, void* stream);
+/* Volume.frag main() (Source/Shaders/Volume.frag:268-314): in-scattering at half resolution
+ * (res_x/2 x res_y/2 pixels, n_samples = gi_enabled ? 8 : 32 samples per pixel), in three calls:
+ *   1. gigl_volume_samples_device: the sample points of every pixel (Volume.frag:283-292), written
+ *      as points[(pixel * n_samples + s)] = (x, y, z, valid); valid = 0 where the shader takes no
+ *      sample (no fog along the ray, or camera-to-sample transmittance <= 0.001);
+ *   2. gigl_shadow_points_device: shadow-map visibility re-expressed as any-hit rays from each
+ *      valid point to each light, Ray{p, normalize(L - p)} over (0, |L - p|); pair index =
+ *      point * n_lights + light, bit layout as gigl_trace_any, invalid points give 0 bits;
+ *   3. gigl_shade_volume_device: the shading sum; vol_comp_rgba: float[4 * (res_x/2) * (res_y/2)].
+ * prim_* are the full-resolution primary rays and hit records (the G-buffer: texel (2x+1, 2y+1)
+ * is used), fog_dist is gigl_shade_surface_device's output for the whole image, rnd_offsets
+ * float[(res_x/2)*(res_y/2)] (the reference fills it with random numbers), halton
+ * float[30 * 32] (Source/Common/Halton.hpp, base 2).  prm->first is ignored.  All device pointers. */
+int gigl_volume_samples_device(const gigl_scene* s, const gigl_fog* fog, const gigl_shade_params* prm,
+                               const void* prim_o_tmin, const void* prim_d_tmax, const gigl_hit* prim_hits,
+                               const float* fog_dist, const float* rnd_offsets, const float* halton,
+                               const float* pi_dens, float* points, void* stream);
+int gigl_shadow_points_device(const gigl_scene* s, const float* points, uint64_t n_pts, const float* lights,
+                              uint32_t n_lights, uint64_t* occluded_bits, void* stream);
+int gigl_shade_volume_device(const gigl_scene* s, const gigl_fog* fog, const gigl_shade_params* prm,
+                             const void* prim_o_tmin, const void* prim_d_tmax, const gigl_hit* prim_hits,
+                             const float* fog_dist, const float* rnd_offsets, const float* halton,
+                             const float* pi_dens, const float* ppls, const void* vpls,
+                             const uint64_t* occluded_bits, float* vol_comp_rgba, void* stream);
 /* Combine.frag:72-76 without the volume term: rgb = 1 - exp(-exposure * accum / (1 + min(frame_id, 30))).
  * rgb_out: float[3*n]. */
 int gigl_tonemap_device(int device, const float* accum_rgba, uint64_t n, int frame_id, int exposure,

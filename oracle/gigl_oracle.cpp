@@ -1124,3 +1124,165 @@ void ora_tonemap(const float* accum_rgba, uint64_t n, int frame_id, int exposure
 }
 
 }  /* extern "C" */
+
+/* ---- Volume.frag main() (Source/Shaders/Volume.frag:268-314).  PARITY UNPINNED, same stand-ins as
+ * the surface pass; shadow-map visibility = any-hit rays from the sample point (ora_shadow_points). */
+namespace {
+struct VolPixel { V3 ray_d; float t_min, t_max, z_offset; int tx, ty; bool fog; };
+struct VolSample { V3 pos; float transm; bool valid; };
+inline VolPixel volume_pixel(const float* po, const float* pd, const Hit16* H, const float* fog_dist,
+                             const float* rnd_offsets, V3 cam, int res_x, int frame_id, int hx, int hy) {
+    VolPixel px;
+    const size_t full = (size_t)(2 * hx + 1) + (size_t)(2 * hy + 1) * res_x;     /* :90, :95 */
+    px.t_min = fog_dist[2 * full]; px.t_max = fog_dist[2 * full + 1];
+    px.fog = px.t_max > 0.0f && frame_id < 30;                                     /* :270, :275 */
+    px.ray_d = v3(0.0f, 0.0f, 0.0f);
+    px.z_offset = 0.0f;
+    /* gl_FragCoord.xy / CAM_RES with `#define CAM_RES 1024 / 2` = (xy / 1024) / 2 (:4, :285) */
+    px.tx = hx >> 1; px.ty = hy >> 1;
+    if (px.fog) {
+        const V3 w_pos = ld3(po + 4 * full) + H[full].t * ld3(pd + 4 * full);
+        px.ray_d = normalize(w_pos - cam);                                         /* :280 */
+        px.z_offset = rnd_offsets[hx + (size_t)hy * (res_x / 2)];                  /* :282 */
+    }
+    return px;
+}
+inline VolSample volume_sample(const ora_fog& F, const VolPixel& px, V3 cam, const float* halton,
+                               const float* pi_dens, int res_x, int res_y, int pi_res_z, int n_samples,
+                               int frame_id, int s) {
+    VolSample smp;
+    const float hz = halton[s + n_samples * frame_id] + px.z_offset;
+    const float z = smin(smax(hz, 0.0f), 0.995f);                                  /* :286 */
+    const float t = px.t_min + z * (px.t_max - px.t_min);
+    smp.pos = cam + t * px.ray_d;
+    smp.transm = expf(-(F.ext_k * pi_dens_fetch(pi_dens, res_x, res_y, pi_res_z, px.tx, px.ty, z)));
+    smp.valid = smp.transm > 0.001f;                                               /* :292 */
+    return smp;
+}
+/* calcTransm, Volume.frag:159-181 */
+inline float glsl_calc_transm_vol(const ora_fog& F, V3 p, float density, V3 dir, float dist_sq, int transm_opt) {
+    if (!transm_opt) return glsl_calc_transm(F, p, dir, dist_sq);
+    float transm = 1.0f;
+    if (F.ext_k > 0.0f) {
+        const float max_dist = sqrtf(dist_sq);
+        float t_min, t_max;
+        if (glsl_intersect_bbox(F, p, dir, max_dist, t_min, t_max)) {
+            t_min = smax(t_min, 0.0f);
+            t_max = smin(t_max, max_dist);
+            transm = expf(-(F.ext_k * density * (t_max - t_min)));
+        }
+    }
+    return transm;
+}
+}  // namespace
+
+extern "C" {
+
+/* Source/Common/Halton.hpp:5-18, base 2 */
+void ora_halton2(float* seq, int n) {
+    for (int i = 0; i < n; ++i) {
+        seq[i] = 0.0f;
+        int den = 2, t = i + 1;
+        while (t > 0) {
+            seq[i] += 1.0f / den * (t % 2);
+            t /= 2;
+            den *= 2;
+        }
+    }
+}
+
+void ora_volume_samples(const ora_fog* fog, const float cam_pos[3], int res_x, int res_y, const float* po,
+                        const float* pd, const void* prim_hits16, const float* fog_dist, const float* rnd_offsets,
+                        const float* halton, const float* pi_dens, int pi_res_z, int gi_enabled, int frame_id,
+                        float* points) {
+    const Hit16* H = (const Hit16*)prim_hits16;
+    const V3 cam = ld3(cam_pos);
+    const int hw = res_x / 2, hh = res_y / 2, n_samples = gi_enabled ? 8 : 32;
+    for (int hy = 0; hy < hh; ++hy)
+        for (int hx = 0; hx < hw; ++hx) {
+            const VolPixel px = volume_pixel(po, pd, H, fog_dist, rnd_offsets, cam, res_x, frame_id, hx, hy);
+            for (int s = 0; s < n_samples; ++s) {
+                float* out = points + 4 * (((size_t)hx + (size_t)hy * hw) * n_samples + s);
+                out[0] = out[1] = out[2] = out[3] = 0.0f;
+                if (!px.fog) continue;
+                const VolSample smp = volume_sample(*fog, px, cam, halton, pi_dens, res_x, res_y, pi_res_z,
+                                                    n_samples, frame_id, s);
+                if (smp.valid) { out[0] = smp.pos.x; out[1] = smp.pos.y; out[2] = smp.pos.z; out[3] = 1.0f; }
+            }
+        }
+}
+
+/* any-hit rays from explicit points to lights: Ray{p, normalize(L - p)} (RTBase.cpp:111-115), range
+ * (0, |L - p|); points with w <= 0 emit no rays (bytes 0xFF). */
+void ora_shadow_points(const ora_scene* s, const float* points, uint64_t n_pts, const float* lights,
+                       uint32_t n_lights, uint8_t* occluded, int n_threads) {
+    const int nt = n_threads < 1 ? 1 : n_threads;
+    (void)nt;
+#pragma omp parallel for schedule(dynamic, 256) num_threads(nt) if (nt > 1)
+    for (int64_t i = 0; i < (int64_t)n_pts; ++i) {
+        uint8_t* occ = occluded + (size_t)i * n_lights;
+        if (!(points[4 * i + 3] > 0.0f)) { for (uint32_t l = 0; l < n_lights; ++l) occ[l] = 0xFF; continue; }
+        const V3 p = ld3(points + 4 * i);
+        for (uint32_t l = 0; l < n_lights; ++l) {
+            const V3 dirv = ld3(lights + 3 * l) - p;
+            const float dist_sq = dot(dirv, dirv);
+            Ray r = make_ray(p, dirv * (1.0f / sqrtf(dist_sq)));
+            r.t_min = 0.0f; r.t_max = sqrtf(dist_sq);
+            occ[l] = scene_trace(*s, r, true) ? 1 : 0;
+        }
+    }
+}
+
+void ora_shade_volume(const ora_fog* fog, const float cam_pos[3], int res_x, int res_y, const float* po,
+                      const float* pd, const void* prim_hits16, const float* fog_dist, const float* rnd_offsets,
+                      const float* halton, const float* pi_dens, int pi_res_z, const float* ppls, uint32_t n_ppls,
+                      const void* vpls, uint32_t n_vpls, const uint8_t* occluded, float sca_k, float sca_albedo,
+                      int gi_enabled, int clamp_rsq, int transm_opt, int frame_id, float* vol_comp_rgba,
+                      int n_threads) {
+    const Hit16* H = (const Hit16*)prim_hits16;
+    const VPL96* V = (const VPL96*)vpls;
+    const uint32_t n_lights = n_ppls + n_vpls;
+    const V3 cam = ld3(cam_pos);
+    const int hw = res_x / 2, hh = res_y / 2, n_samples = gi_enabled ? 8 : 32;
+    const V3 dm = fog_max(*fog) - fog_min(*fog);
+    const V3 inv_dims = v3(1.0f / dm.x, 1.0f / dm.y, 1.0f / dm.z);
+    const int nt = n_threads < 1 ? 1 : n_threads;
+    (void)nt;
+#pragma omp parallel for schedule(dynamic, 8) num_threads(nt) if (nt > 1)
+    for (int hy = 0; hy < hh; ++hy)
+        for (int hx = 0; hx < hw; ++hx) {
+            const size_t pix = (size_t)hx + (size_t)hy * hw;
+            const VolPixel px = volume_pixel(po, pd, H, fog_dist, rnd_offsets, cam, res_x, frame_id, hx, hy);
+            V3 col = v3(0.0f, 0.0f, 0.0f);
+            if (px.fog) {
+                const V3 O = -px.ray_d;
+                for (int s = 0; s < n_samples; ++s) {
+                    const VolSample smp = volume_sample(*fog, px, cam, halton, pi_dens, res_x, res_y, pi_res_z,
+                                                        n_samples, frame_id, s);
+                    if (!smp.valid) continue;
+                    const float density = fog_filter(*fog, (smp.pos - fog_min(*fog)) * inv_dims);   /* :121-126 */
+                    for (uint32_t l = 0; l < n_lights; ++l) {
+                        const bool is_ppl = l < n_ppls;
+                        if (is_ppl ? !clamp_rsq : !gi_enabled) continue;
+                        if (occluded[(pix * n_samples + s) * n_lights + l]) continue;
+                        const V3 L = is_ppl ? ld3(ppls + 8 * l) : ld3(V[l - n_ppls].w_pos);
+                        const V3 dd = smp.pos - L;
+                        const float dist_sq = dot(dd, dd);
+                        const V3 I = normalize(-dd);
+                        const float tr = glsl_calc_transm_vol(*fog, smp.pos, density, I, dist_sq, transm_opt);
+                        V3 Li;
+                        if (is_ppl) Li = (tr * ld3(ppls + 8 * l + 4)) * (1.0f / dist_sq);
+                        else Li = (tr * glsl_compute_le(V[l - n_ppls], -I, sca_albedo)) * (1.0f / smax(dist_sq, 75.0f * 75.0f));
+                        const float cos_the = -dot(I, O);
+                        const V3 c = ((glsl_phase_hg(cos_the) * sca_k) * density) * Li;
+                        col = col + smp.transm * c;
+                    }
+                }
+                col = col * ((px.t_max - px.t_min) / (float)n_samples);
+            }
+            float* out = vol_comp_rgba + 4 * pix;
+            out[0] = col.x; out[1] = col.y; out[2] = col.z; out[3] = 1.0f;
+        }
+}
+
+}  /* extern "C" */

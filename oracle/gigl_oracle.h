@@ -144,6 +144,25 @@ void ora_shade_surface(const ora_scene* s, const ora_fog* fog, const float cam_p
                        int n_threads);
 void ora_tonemap(const float* accum_rgba, uint64_t n, int frame_id, int exposure, float* rgb);
 
+/* Volume.frag main() (Source/Shaders/Volume.frag:268-314) in the three steps of the engine's ABI
+ * (gigl_volume_samples_device, gigl_shadow_points_device, gigl_shade_volume_device).  PARITY
+ * UNPINNED.  points: float[4 * (res_x/2)*(res_y/2) * n_samples], n_samples = gi_enabled ? 8 : 32;
+ * occluded: uint8 per (point, light). */
+void ora_halton2(float* seq, int n);   /* Source/Common/Halton.hpp, base 2 */
+void ora_volume_samples(const ora_fog* fog, const float cam_pos[3], int res_x, int res_y,
+                        const float* prim_o_tmin, const float* prim_d_tmax, const void* prim_hits16,
+                        const float* fog_dist, const float* rnd_offsets, const float* halton,
+                        const float* pi_dens, int pi_res_z, int gi_enabled, int frame_id, float* points);
+void ora_shadow_points(const ora_scene* s, const float* points, uint64_t n_pts, const float* lights,
+                       uint32_t n_lights, uint8_t* occluded, int n_threads);
+void ora_shade_volume(const ora_fog* fog, const float cam_pos[3], int res_x, int res_y,
+                      const float* prim_o_tmin, const float* prim_d_tmax, const void* prim_hits16,
+                      const float* fog_dist, const float* rnd_offsets, const float* halton,
+                      const float* pi_dens, int pi_res_z, const float* ppls, uint32_t n_ppls,
+                      const void* vpls, uint32_t n_vpls, const uint8_t* occluded, float sca_k,
+                      float sca_albedo, int gi_enabled, int clamp_rsq, int transm_opt, int frame_id,
+                      float* vol_comp_rgba, int n_threads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -74,6 +74,12 @@ def lib():
                                         C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                         C.c_int]
         L.ora_tonemap.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_void_p]
+        vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+        L.ora_halton2.argtypes = [vp, ci]
+        L.ora_volume_samples.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp]
+        L.ora_shadow_points.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint32, vp, ci]
+        L.ora_shade_volume.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, ci, vp, C.c_uint32, vp,
+                                       C.c_uint32, vp, cf, cf, ci, ci, ci, ci, vp, ci]
         _LIB = L
     return _LIB
 
@@ -280,3 +286,49 @@ def tonemap(accum, frame_id, exposure):
     rgb = np.zeros((len(accum), 3), np.float32)
     lib().ora_tonemap(_p(accum), len(accum), frame_id, exposure, _p(rgb))
     return rgb
+
+
+def halton2(n=30 * 32):
+    """HaltonSG::generate<2> (Source/Common/Halton.hpp): the volume pass's sample offsets."""
+    seq = np.zeros(n, np.float32)
+    lib().ora_halton2(_p(seq), n)
+    return seq
+
+
+def volume_samples(fog, cam_pos, res_x, res_y, ro, rd, hits, fog_dist, rnd_offsets, halton, pi_dens,
+                   gi_enabled=True, frame_id=0):
+    """Sample points of Volume.frag (see ora_volume_samples): (n_pixels * n_samples, 4) = x, y, z, valid."""
+    ro, rd = _f32(ro).reshape(-1, 4), _f32(rd).reshape(-1, 4)
+    hits = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
+    pi_dens = _f32(pi_dens)
+    n_samples = 8 if gi_enabled else 32
+    pts = np.zeros(((res_x // 2) * (res_y // 2) * n_samples, 4), np.float32)
+    lib().ora_volume_samples(fog.ref(), _p(_f32(cam_pos)), res_x, res_y, _p(ro), _p(rd), _p(hits),
+                             _p(_f32(fog_dist)), _p(_f32(rnd_offsets)), _p(_f32(halton)), _p(pi_dens),
+                             pi_dens.shape[0], int(gi_enabled), frame_id, _p(pts))
+    return pts
+
+
+def shadow_points(scene, points, lights, n_threads=1):
+    points, lights = _f32(points).reshape(-1, 4), _f32(lights).reshape(-1, 3)
+    occ = np.zeros((len(points), len(lights)), np.uint8)
+    lib().ora_shadow_points(scene.h, _p(points), len(points), _p(lights), len(lights), _p(occ), n_threads)
+    return occ
+
+
+def shade_volume(fog, cam_pos, res_x, res_y, ro, rd, hits, fog_dist, rnd_offsets, halton, pi_dens, ppls, vpls,
+                 occluded, sca_k, sca_albedo, gi_enabled=True, clamp_rsq=True, transm_opt=True, frame_id=0,
+                 n_threads=1):
+    """Volume.frag main() (see ora_shade_volume); returns vol_comp (n_half_res_pixels, 4)."""
+    ro, rd = _f32(ro).reshape(-1, 4), _f32(rd).reshape(-1, 4)
+    hits = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
+    pi_dens = _f32(pi_dens)
+    ppls = _f32(ppls).reshape(-1, 8)
+    vpls = np.ascontiguousarray(vpls, dtype=VPL_DTYPE)
+    occluded = np.ascontiguousarray(occluded, dtype=np.uint8)
+    out = np.zeros(((res_x // 2) * (res_y // 2), 4), np.float32)
+    lib().ora_shade_volume(fog.ref(), _p(_f32(cam_pos)), res_x, res_y, _p(ro), _p(rd), _p(hits), _p(_f32(fog_dist)),
+                           _p(_f32(rnd_offsets)), _p(_f32(halton)), _p(pi_dens), pi_dens.shape[0], _p(ppls),
+                           len(ppls), _p(vpls), len(vpls), _p(occluded), sca_k, sca_albedo, int(gi_enabled),
+                           int(clamp_rsq), int(transm_opt), frame_id, _p(out), n_threads)
+    return out

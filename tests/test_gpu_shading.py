@@ -125,3 +125,81 @@ def test_shade_surface_argument_errors(cornell):
     with pytest.raises(rt.GiglError):   # pixel range outside the image
         scene.shade_surface_device(prm, p, p, p, 4, p, 1, p, None, p, p)
     scene.close()
+
+
+@pytest.mark.parametrize("gi,transm_opt,frame_id", [(True, True, 0), (False, True, 2), (True, False, 5)])
+def test_shade_volume_cornell(cornell, oracle_cornell, density, fog_box, gi, transm_opt, frame_id):
+    """Volume.frag main() through the three device calls (sample points, point-light any-hit rays,
+    shading) against the oracle, at 128 x 128 (64 x 64 half-resolution pixels x 8 or 32 samples x 151
+    lights).  Sample points and occlusion bits are compared bit for bit, colours to 1e-5."""
+    torch = pytest.importorskip("torch")
+    res, hw = 128, 64
+    cam = O.camera_setup(S.CAM_POS, S.CAM_DIR, S.CAM_UP, S.CAM_HFOV, res, res)
+    vp = np.load(os.path.join(GOLDEN, "vpl_set.npz"))
+    vpls = vp["vpls"].view(O.VPL_DTYPE).reshape(-1)
+    ppls = np.zeros((1, 8), np.float32)
+    ppls[0, :3], ppls[0, 4:7] = S.PRIM_PL_POS, S.PRIM_PL_INTENS
+    lights = np.concatenate([ppls[:, :3], vp["vpls"].view(np.float32)[:, :3]]).astype(np.float32)
+    n_lights, n_samples = len(lights), (8 if gi else 32)
+    ext_k = np.float32(S.ABS_K) + np.float32(S.SCA_K)
+    sca_albedo, sca_k = float(np.float32(S.SCA_K) / ext_k), float(np.float32(S.SCA_K))
+    fog_o, fog_g = O.Fog(density, fog_box, ext_k), rt.FogVolume(density, fog_box, S.ABS_K, S.SCA_K)
+    scene = rt.Scene(cornell["verts"], cornell["tris"], device=0, **S.KD_PARAMS)
+    sh = torch.cuda.current_stream().cuda_stream
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    n = res * res
+    ro, rd = O.primary_rays(cam, res, 0, n)
+    hits = oracle_cornell.trace_closest(ro, rd, n_threads=4)
+    rnd = (np.float32(0.03) * np.random.default_rng(9).random(hw * hw, dtype=np.float32) - np.float32(0.015))
+    hal = O.halton2()
+    # ---- device: pi_dens, surface pass (for fog_dist), then the three volume calls ----
+    d_o, d_d = t(ro), t(rd)
+    d_h = torch.zeros((n, 4), dtype=torch.int32, device="cuda:0")
+    scene.trace_closest_device(d_o.data_ptr(), d_d.data_ptr(), n, d_h.data_ptr(), sh)
+    pi_g = torch.zeros(64 * n, dtype=torch.float32, device="cuda:0")
+    scene.compute_pi_density_device(fog_g, cam, res, res, pi_g.data_ptr(), sh)
+    prm = rt.ShadeParams()
+    prm.cam_pos[:] = S.CAM_POS
+    prm.res_x = prm.res_y = res
+    prm.first, prm.n_ppls, prm.n_vpls = 0, 0, 0
+    prm.gi_enabled, prm.clamp_rsq, prm.frame_id, prm.pi_res_z = int(gi), 1, frame_id, 64
+    prm.sca_albedo, prm.transm_opt, prm.sca_k = sca_albedo, int(transm_opt), sca_k
+    accum = torch.zeros((n, 4), dtype=torch.float32, device="cuda:0")
+    fd = torch.zeros((n, 2), dtype=torch.float32, device="cuda:0")
+    d_mat = t(cornell["materials"])
+    scene.shade_surface_device(prm, d_o.data_ptr(), d_d.data_ptr(), d_h.data_ptr(), n, d_mat.data_ptr(),
+                               len(cornell["materials"]), None, None, None, accum.data_ptr(), fog=fog_g,
+                               pi_dens_ptr=pi_g.data_ptr(), fog_dist_ptr=fd.data_ptr(), stream=sh)
+    prm.n_ppls, prm.n_vpls = 1, len(vpls)
+    d_rnd, d_hal, d_l, d_ppl, d_vpl = t(rnd), t(hal), t(lights), t(ppls), t(vp["vpls"].view(np.int32))
+    n_pts = hw * hw * n_samples
+    pts = torch.zeros((n_pts, 4), dtype=torch.float32, device="cuda:0")
+    scene.volume_samples_device(fog_g, prm, d_o.data_ptr(), d_d.data_ptr(), d_h.data_ptr(), fd.data_ptr(),
+                                d_rnd.data_ptr(), d_hal.data_ptr(), pi_g.data_ptr(), pts.data_ptr(), sh)
+    bits = torch.zeros((n_pts * n_lights + 63) // 64, dtype=torch.int64, device="cuda:0")
+    scene.shadow_points_device(pts.data_ptr(), n_pts, d_l.data_ptr(), n_lights, bits.data_ptr(), sh)
+    vol = torch.zeros((hw * hw, 4), dtype=torch.float32, device="cuda:0")
+    scene.shade_volume_device(fog_g, prm, d_o.data_ptr(), d_d.data_ptr(), d_h.data_ptr(), fd.data_ptr(),
+                              d_rnd.data_ptr(), d_hal.data_ptr(), pi_g.data_ptr(), d_ppl.data_ptr(), d_vpl.data_ptr(),
+                              bits.data_ptr(), vol.data_ptr(), sh)
+    torch.cuda.synchronize()
+    # ---- oracle on the same pi_dens and fog_dist (each compared with its own oracle elsewhere) ----
+    pi_o, fd_o = pi_g.cpu().numpy().reshape(64, res, res), fd.cpu().numpy()
+    want_pts = O.volume_samples(fog_o, S.CAM_POS, res, res, ro, rd, hits, fd_o, rnd, hal, pi_o, gi_enabled=gi,
+                                frame_id=frame_id)
+    got_pts = pts.cpu().numpy()
+    assert np.array_equal(got_pts[:, 3], want_pts[:, 3]) and (want_pts[:, 3] > 0).mean() > 0.3
+    assert _close(got_pts[:, :3], want_pts[:, :3])
+    # visibility from the oracle's own points where they are bit-identical (they are: checked next)
+    assert np.array_equal(got_pts.view(np.uint32), want_pts.view(np.uint32))
+    want_occ = O.shadow_points(oracle_cornell, want_pts, lights, n_threads=4)
+    got_occ = rt.unpack_bits(bits.cpu().numpy().view(np.uint64), n_pts * n_lights).reshape(n_pts, n_lights)
+    assert np.array_equal(got_occ, np.where(want_occ == 0xFF, 0, want_occ))
+    want = O.shade_volume(fog_o, S.CAM_POS, res, res, ro, rd, hits, fd_o, rnd, hal, pi_o, ppls, vpls, want_occ,
+                          sca_k, sca_albedo, gi_enabled=gi, clamp_rsq=True, transm_opt=transm_opt, frame_id=frame_id,
+                          n_threads=4)
+    got = vol.cpu().numpy()
+    assert (got[:, 3] == 1.0).all() and (want[:, :3].sum(1) > 0).mean() > 0.3
+    assert _close(got[:, :3], want[:, :3]), float(np.abs(got[:, :3] - want[:, :3]).max())
+    fog_g.close()
+    scene.close()

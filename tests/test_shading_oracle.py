@@ -64,3 +64,52 @@ def test_tonemap():
     want = 1.0 - np.exp(-2.0 * a[:, :3].astype(np.float64) / 4.0)
     assert np.allclose(rgb, want, rtol=1e-6, atol=1e-7)
     assert np.array_equal(O.tonemap(a, 40, 2), O.tonemap(a, 30, 2))
+
+
+def test_halton_base2():
+    h = O.halton2(30 * 32)
+    assert h.dtype == np.float32 and len(h) == 960
+    assert np.array_equal(h[:7], np.array([0.5, 0.25, 0.75, 0.125, 0.625, 0.375, 0.875], np.float32))
+    assert (h > 0).all() and (h < 1).all() and len(np.unique(h)) == 960     # radical inverse: all distinct
+
+
+def test_shade_volume_properties(cornell, oracle_cornell, density, fog_box):
+    c = _setup(cornell, oracle_cornell, density, fog_box)
+    res, n = c["res"], c["res"] ** 2
+    _, fd = O.shade_surface(oracle_cornell, c["fog"], S.CAM_POS, res, res, 0, c["ro"], c["rd"], c["hits"],
+                            cornell["materials"], c["ppls"], c["vpls"], c["occ"], transm=c["tr"], pi_dens=c["pi"],
+                            sca_albedo=c["albedo"], n_threads=4)
+    hw = res // 2
+    rnd = (np.float32(0.03) * np.random.default_rng(3).random(hw * hw, dtype=np.float32) - np.float32(0.015))
+    hal = O.halton2()
+    lights = np.concatenate([c["ppls"][:, :3], c["vpls"].view(np.float32).reshape(-1, 24)[:, :3]]).astype(np.float32)
+    pts = O.volume_samples(c["fog"], S.CAM_POS, res, res, c["ro"], c["rd"], c["hits"], fd, rnd, hal, c["pi"])
+    assert pts.shape == (hw * hw * 8, 4)
+    valid = pts[:, 3] > 0
+    assert 0.3 < valid.mean() <= 1.0
+    box = np.asarray(fog_box)
+    eps = 1e-3 * (box[3:] - box[:3])
+    assert ((pts[valid, :3] >= box[:3] - eps) & (pts[valid, :3] <= box[3:] + eps)).all()   # samples lie in the fog box
+    assert (pts[~valid] == 0).all()
+    # pixels whose full-resolution texel (2x+1, 2y+1) recorded no fog interval take no sample
+    fd_half = fd.reshape(res, res, 2)[1::2, 1::2].reshape(-1, 2)
+    assert (~valid.reshape(-1, 8)[fd_half[:, 1] <= 0]).all()
+    occ = O.shadow_points(oracle_cornell, pts, lights, n_threads=4)
+    assert (occ[~valid] == 0xFF).all() and set(np.unique(occ[valid])) <= {0, 1}
+    assert 0.02 < occ[valid].mean() < 0.98
+    kw = dict(sca_k=float(np.float32(S.SCA_K)), sca_albedo=c["albedo"], n_threads=4)
+    args = (c["fog"], S.CAM_POS, res, res, c["ro"], c["rd"], c["hits"], fd, rnd, hal, c["pi"], c["ppls"], c["vpls"], occ)
+    vol = O.shade_volume(*args, **kw)
+    assert vol.shape == (hw * hw, 4) and np.isfinite(vol).all() and (vol[:, :3] >= 0).all() and (vol[:, 3] == 1).all()
+    lit = vol[:, :3].sum(1) > 0
+    assert lit.any() and not lit[fd_half[:, 1] <= 0].any()
+    # the constant-medium shortcut and the ray march are two estimators of the same transmittance:
+    # same lit pixels, totals of the same magnitude, not the same numbers
+    marched = O.shade_volume(*args, transm_opt=False, **kw)
+    assert np.array_equal(marched[:, :3].sum(1) > 0, lit)
+    assert 0.3 < marched[:, :3].sum() / vol[:, :3].sum() < 3.0 and not np.array_equal(marched, vol)
+    # everything occluded -> nothing scattered in
+    dark = O.shade_volume(*args[:-1], np.ones_like(occ), **kw)
+    assert (dark[:, :3] == 0).all()
+    # frame cap (Volume.frag:270)
+    assert (O.shade_volume(*args, frame_id=29, **kw)[:, :3].sum() > 0)
