@@ -300,21 +300,50 @@ def extras(torch, rt, S, scene, d_o, d_d, n, device):
     prm.gi_enabled, prm.clamp_rsq, prm.frame_id, prm.pi_res_z = 1, 1, 0, 64
     prm.sca_albedo = float(np.float32(S.SCA_K) / (np.float32(S.ABS_K) + np.float32(S.SCA_K)))
 
+    # the volume pass (Volume.frag at 512^2 x 8 samples x 151 lights) and Combine.frag
+    fd = torch.zeros((npix, 2), dtype=torch.float32, device=device)
+    hal = up(O.halton2())
+    rnd = up(np.float32(0.03) * np.random.default_rng(7).random(512 * 512, dtype=np.float32) - np.float32(0.015))
+    n_vp = 512 * 512 * 8
+    pts = torch.zeros((n_vp, 4), dtype=torch.float32, device=device)
+    vbits = torch.zeros((n_vp * 151 + 63) // 64, dtype=torch.int64, device=device)
+    vol = torch.zeros((512 * 512, 4), dtype=torch.float32, device=device)
+    depth = torch.zeros(npix, dtype=torch.float32, device=device)
+    prm.transm_opt, prm.sca_k = 1, float(np.float32(S.SCA_K))
+    ext_k = float(np.float32(S.ABS_K) + np.float32(S.SCA_K))
+
     def shade():
         cs.shade_surface_device(prm, po.data_ptr(), pd.data_ptr(), ph.data_ptr(), npix, d_mat.data_ptr(), len(mats),
                                 d_ppl.data_ptr(), d_vpl.data_ptr(), sb.data_ptr(), accum.data_ptr(), fog=fog,
-                                transm_ptr=tr.data_ptr(), pi_dens_ptr=pi.data_ptr(), stream=sh)
-        rt.tonemap_device(accum.data_ptr(), npix, 0, 12, rgb.data_ptr(), device=device.index, stream=sh)
+                                transm_ptr=tr.data_ptr(), pi_dens_ptr=pi.data_ptr(), fog_dist_ptr=fd.data_ptr(), stream=sh)
 
-    def frame():
+    def volume():
+        cs.volume_samples_device(fog, prm, po.data_ptr(), pd.data_ptr(), ph.data_ptr(), fd.data_ptr(), rnd.data_ptr(),
+                                 hal.data_ptr(), pi.data_ptr(), pts.data_ptr(), sh)
+        cs.shadow_points_device(pts.data_ptr(), n_vp, d_l.data_ptr(), 151, vbits.data_ptr(), sh)
+        cs.shade_volume_device(fog, prm, po.data_ptr(), pd.data_ptr(), ph.data_ptr(), fd.data_ptr(), rnd.data_ptr(),
+                               hal.data_ptr(), pi.data_ptr(), d_ppl.data_ptr(), d_vpl.data_ptr(), vbits.data_ptr(),
+                               vol.data_ptr(), sh)
+
+    def combine():
+        rt.depth_buffer_device(S.CAM_POS, S.CAM_DIR, 0.1, 2500.0, po.data_ptr(), pd.data_ptr(), ph.data_ptr(), npix,
+                               depth.data_ptr(), device=device.index, stream=sh)
+        rt.combine_device(1024, 1024, depth.data_ptr(), vol.data_ptr(), ext_k, 0, 12, accum.data_ptr(), rgb.data_ptr(),
+                          device=device.index, stream=sh)
+
+    def frame():   # frame 0 of the reference's render loop, every pass
         cs.trace_primary_device(cam, 1024, 0, npix, ph.data_ptr(), sh)
         cs.shadow_batch_device(po.data_ptr(), pd.data_ptr(), ph.data_ptr(), npix, d_l.data_ptr(), 151, sb.data_ptr(),
                                fog=fog, transm_ptr=tr.data_ptr(), stream=sh)
         shade()
+        volume()
+        combine()
 
     frame()
     res["cornell_shade_surface_ms"] = round(timeit(shade, reps=2), 3)
-    res["cornell_frame_ms"] = round(timeit(frame, reps=2), 3)   # primary + 151 shadow rays/pixel + march + shade
+    res["cornell_volume_pass_ms"] = round(timeit(volume, reps=2), 3)   # 2.1 M sample points, 317 M any-hit rays
+    res["cornell_combine_ms"] = round(timeit(combine, reps=2), 3)
+    res["cornell_frame_ms"] = round(timeit(frame, reps=2), 3)
     res["cornell_frame_mean_rgb"] = [round(float(x), 5) for x in rgb.mean(0).tolist()]
     fog.close()
     cs.close()

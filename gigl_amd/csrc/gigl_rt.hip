@@ -1120,6 +1120,78 @@ __global__ void __launch_bounds__(256) shade_volume_kernel(FogParams F, VolumePa
     }
 }
 
+// ---- Combine.frag (Source/Shaders/Combine.frag:23-77) --------------------------------------------
+// GL depth of the primary hit point: lookAt + glm::perspective (Camera.cpp:30-31), quantised to
+// DEPTH_COMPONENT24 (GLTexture2D.h:27); 1.0 (the cleared value) where the primary ray missed.
+__global__ void __launch_bounds__(256) depth_kernel(F3 cam, F3 fwd, float t_near, float t_far,
+                                                    const float4* __restrict__ prim_o, const float4* __restrict__ prim_d,
+                                                    const uint4* __restrict__ hits, unsigned n, float* __restrict__ depth) {
+    const float A = -(t_far + t_near) / (t_far - t_near), B = -(2.0f * t_far * t_near) / (t_far - t_near);
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const uint4 h = hits[i];
+        float d = 1.0f;
+        if (h.x != kMiss) {
+            const float4 o = prim_o[i], dir = prim_d[i];
+            const F3 w_pos = f3(o.x, o.y, o.z) + __uint_as_float(h.y) * f3(dir.x, dir.y, dir.z);
+            const float z_e = -dot3(fwd, w_pos - cam);
+            const float z_ndc = (A * z_e + B) / -z_e;
+            d = floorf((0.5f * z_ndc + 0.5f) * 16777215.0f + 0.5f) / 16777215.0f;
+        }
+        depth[i] = d;
+    }
+}
+
+__device__ __forceinline__ F3 vol_texel(const float4* vol, int hw, int hh, int x, int y) {  // CLAMP_TO_BORDER, border 0
+    if (x < 0 || x >= hw || y < 0 || y >= hh) return f3(0.0f, 0.0f, 0.0f);
+    const float4 t = vol[(size_t)x + (size_t)y * hw];
+    return f3(t.x, t.y, t.z);
+}
+
+__global__ void __launch_bounds__(256) combine_kernel(unsigned res_x, unsigned res_y, const float* __restrict__ depth,
+                                                      const float4* __restrict__ vol, int add, int frame_id,
+                                                      int exposure, float4* accum, float* __restrict__ rgb) {
+    const int hw = (int)(res_x / 2u), hh = (int)(res_y / 2u);
+    const float div = (float)(1 + (frame_id < 30 ? frame_id : 30));
+    const unsigned n = res_x * res_y;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const int x = (int)(i % res_x), y = (int)(i / res_x);
+        const float4 a4 = accum[i];
+        F3 c = f3(a4.x, a4.y, a4.z);
+        if (add) {                                       // bilateralUpsampling, :24-49
+            const float center_depth = depth[i];
+            float accum_weight = 0.0f;
+            F3 acc = f3(0.0f, 0.0f, 0.0f);
+            for (int dy = -1; dy <= 1; ++dy)
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int px = x + dx, py = y + dy;
+                    const bool inside = px >= 0 && px < (int)res_x && py >= 0 && py < (int)res_y;
+                    const float dpt = inside ? depth[(size_t)px + (size_t)py * res_x] : 0.0f;
+                    // texture(vol_comp, vec2(pos) / CAM_RES), bilinear
+                    const float fu = ((float)px / (float)res_x) * (float)hw - 0.5f;
+                    const float fv = ((float)py / (float)res_y) * (float)hh - 0.5f;
+                    const float x0f = floorf(fu), y0f = floorf(fv);
+                    const int x0 = (int)x0f, y0 = (int)y0f;
+                    const float a = fu - x0f, b = fv - y0f;
+                    const F3 t00 = vol_texel(vol, hw, hh, x0, y0), t10 = vol_texel(vol, hw, hh, x0 + 1, y0);
+                    const F3 t01 = vol_texel(vol, hw, hh, x0, y0 + 1), t11 = vol_texel(vol, hw, hh, x0 + 1, y0 + 1);
+                    const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+                    const F3 col = f3(((w00 * t00.x + w10 * t10.x) + w01 * t01.x) + w11 * t11.x,
+                                      ((w00 * t00.y + w10 * t10.y) + w01 * t01.y) + w11 * t11.y,
+                                      ((w00 * t00.z + w10 * t10.z) + w01 * t01.z) + w11 * t11.z);
+                    const float weight = (1.0f - 0.3f * (float)abs(dx)) * (1.0f - 0.3f * (float)abs(dy)) /
+                                         (smax(dpt - center_depth, 0.0f) * 1000.0f + 1.0f);
+                    accum_weight += weight;
+                    acc = f3(acc.x + weight * col.x, acc.y + weight * col.y, acc.z + weight * col.z);
+                }
+            c = f3(c.x + acc.x / accum_weight, c.y + acc.y / accum_weight, c.z + acc.z / accum_weight);
+            accum[i] = make_float4(c.x, c.y, c.z, 1.0f);                                      // :69
+        }
+        rgb[3 * (size_t)i] = 1.0f - expf(-(float)exposure * (c.x / div));                     // :73-75
+        rgb[3 * (size_t)i + 1] = 1.0f - expf(-(float)exposure * (c.y / div));
+        rgb[3 * (size_t)i + 2] = 1.0f - expf(-(float)exposure * (c.z / div));
+    }
+}
+
 // Combine.frag:72-76 (without the volume term)
 __global__ void __launch_bounds__(256) tonemap_kernel(const float4* __restrict__ accum, unsigned n, int frame_id,
                                                       int exposure, float* __restrict__ rgb) {
@@ -1991,6 +2063,42 @@ int gigl_shade_volume_device(const gigl_scene* s, const gigl_fog* fog, const gig
     V.ppls = ppls; V.vpls = (const float*)vpls; V.bits = (const unsigned long long*)occluded_bits;
     V.vol_comp = (float4*)vol_comp_rgba;
     hipLaunchKernelGGL(shade_volume_kernel, dim3(stream_grid(s, n_pix)), dim3(256), 0, (hipStream_t)stream, fog->fp, V);
+    HIP_TRY(hipGetLastError());
+    return GIGL_OK;
+}
+
+int gigl_depth_buffer_device(int device, const float cam_pos[3], const float cam_dir[3], float t_near, float t_far,
+                             const void* prim_o_tmin, const void* prim_d_tmax, const gigl_hit* prim_hits, uint64_t n,
+                             float* depth, void* stream) {
+    if (n == 0) return GIGL_OK;
+    if (!cam_pos || !cam_dir || !prim_o_tmin || !prim_d_tmax || !prim_hits || !depth) return fail(GIGL_ERR_INVALID, "NULL argument");
+    if (n > kMaxRays) return fail(GIGL_ERR_TOO_LARGE, "at most 0xF0000000 pixels per call");
+    if (!(t_far > t_near) || !(t_near > 0.0f)) return fail(GIGL_ERR_INVALID, "need 0 < t_near < t_far");
+    DeviceGuard g(device);
+    if (!g.ok) return fail(GIGL_ERR_NO_DEVICE, "hipSetDevice failed");
+    const float sq = cam_dir[0] * cam_dir[0] + cam_dir[1] * cam_dir[1] + cam_dir[2] * cam_dir[2];
+    const float inv = 1.0f / sqrtf(sq);                      // glm::normalize, on the host as in Camera.cpp:21
+    const F3 fwd = {cam_dir[0] * inv, cam_dir[1] * inv, cam_dir[2] * inv};
+    const F3 cam = {cam_pos[0], cam_pos[1], cam_pos[2]};
+    hipLaunchKernelGGL(depth_kernel, dim3(stream_grid(nullptr, n)), dim3(256), 0, (hipStream_t)stream, cam, fwd, t_near,
+                       t_far, (const float4*)prim_o_tmin, (const float4*)prim_d_tmax, (const uint4*)prim_hits, (unsigned)n,
+                       depth);
+    HIP_TRY(hipGetLastError());
+    return GIGL_OK;
+}
+
+int gigl_combine_device(int device, int res_x, int res_y, const float* depth, const float* vol_comp_rgba, float ext_k,
+                        int frame_id, int exposure, float* accum_rgba, float* rgb_out, void* stream) {
+    if (res_x < 2 || res_y < 2 || (res_x & 1) || (res_y & 1)) return fail(GIGL_ERR_INVALID, "need an even resolution");
+    if ((uint64_t)res_x * (uint64_t)res_y > (1ull << 28)) return fail(GIGL_ERR_TOO_LARGE, "at most 2^28 pixels");
+    if (!accum_rgba || !rgb_out) return fail(GIGL_ERR_INVALID, "NULL argument");
+    const int add = frame_id < 30 && ext_k > 0.0f;                                            // Combine.frag:65
+    if (add && (!depth || !vol_comp_rgba)) return fail(GIGL_ERR_INVALID, "fog on: depth and vol_comp are required");
+    DeviceGuard g(device);
+    if (!g.ok) return fail(GIGL_ERR_NO_DEVICE, "hipSetDevice failed");
+    hipLaunchKernelGGL(combine_kernel, dim3(stream_grid(nullptr, (uint64_t)res_x * res_y)), dim3(256), 0,
+                       (hipStream_t)stream, (unsigned)res_x, (unsigned)res_y, depth, (const float4*)vol_comp_rgba, add,
+                       frame_id, exposure, (float4*)accum_rgba, rgb_out);
     HIP_TRY(hipGetLastError());
     return GIGL_OK;
 }

@@ -26,6 +26,7 @@ SYMBOLS = [
     "gigl_fog_destroy", "gigl_transmittance_device", "gigl_sample_density", "gigl_debug_rescaled_eps",
     "gigl_set_option", "gigl_debug_last_stats", "gigl_compute_pi_density_device", "gigl_shade_surface_device",
     "gigl_tonemap_device", "gigl_volume_samples_device", "gigl_shadow_points_device", "gigl_shade_volume_device",
+    "gigl_depth_buffer_device", "gigl_combine_device",
 ]
 
 
@@ -96,6 +97,8 @@ def lib():
         L.gigl_volume_samples_device.argtypes = [vp] * 12
         L.gigl_shadow_points_device.argtypes = [vp, vp, u64, vp, u32, vp, vp]
         L.gigl_shade_volume_device.argtypes = [vp] * 15
+        L.gigl_depth_buffer_device.argtypes = [i, vp, vp, f, f, vp, vp, vp, u64, vp, vp]
+        L.gigl_combine_device.argtypes = [i, i, i, vp, vp, f, i, i, vp, vp, vp]
         for s in SYMBOLS:
             if s != "gigl_last_error":
                 getattr(L, s).restype = C.c_int
@@ -151,6 +154,19 @@ def debug_rescaled_eps(t, device=0):
 def tonemap_device(accum_ptr, n, frame_id, exposure, rgb_ptr, device=0, stream=0):
     """Combine.frag:72-76 without the volume term."""
     _check(lib().gigl_tonemap_device(device, accum_ptr, n, frame_id, exposure, rgb_ptr, stream))
+
+
+def depth_buffer_device(cam_pos, cam_dir, t_near, t_far, o_ptr, d_ptr, hits_ptr, n, depth_ptr, device=0, stream=0):
+    """The GL depth buffer's stand-in for Combine.frag (see include/gigl_rt.h)."""
+    _check(lib().gigl_depth_buffer_device(device, _p(_f32(cam_pos)), _p(_f32(cam_dir)), t_near, t_far, o_ptr, d_ptr,
+                                          hits_ptr, n, depth_ptr, stream))
+
+
+def combine_device(res_x, res_y, depth_ptr, vol_comp_ptr, ext_k, frame_id, exposure, accum_ptr, rgb_ptr, device=0,
+                   stream=0):
+    """Combine.frag (Source/Shaders/Combine.frag:23-77)."""
+    _check(lib().gigl_combine_device(device, res_x, res_y, depth_ptr, vol_comp_ptr, ext_k, frame_id, exposure,
+                                     accum_ptr, rgb_ptr, stream))
 
 
 def unpack_bits(words, n):

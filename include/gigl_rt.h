@@ -192,6 +192,18 @@ int gigl_shade_volume_device(const gigl_scene* s, const gigl_fog* fog, const gig
                              const float* fog_dist, const float* rnd_offsets, const float* halton,
                              const float* pi_dens, const float* ppls, const void* vpls,
                              const uint64_t* occluded_bits, float* vol_comp_rgba, void* stream);
+/* Combine.frag (Source/Shaders/Combine.frag:23-77): bilateral upsampling of the half-resolution
+ * volume term onto the accumulation buffer (when frame_id < 30 and ext_k > 0), then normalisation
+ * and tone mapping.  depth: float[res_x*res_y] from gigl_depth_buffer_device — the GL depth buffer's
+ * stand-in: lookAt + glm::perspective depth of the primary hit point (Source/Common/Camera.cpp:30-31;
+ * t_near, t_far = 0.1, 2500 at Source/GIGL.cpp:41) quantised to 24 bits, 1.0 where the ray missed.
+ * accum_rgba is updated in place as writeToAccumBuffer does; rgb_out: float[3*res_x*res_y]. */
+int gigl_depth_buffer_device(int device, const float cam_pos[3], const float cam_dir[3], float t_near,
+                             float t_far, const void* prim_o_tmin, const void* prim_d_tmax,
+                             const gigl_hit* prim_hits, uint64_t n, float* depth, void* stream);
+int gigl_combine_device(int device, int res_x, int res_y, const float* depth, const float* vol_comp_rgba,
+                        float ext_k, int frame_id, int exposure, float* accum_rgba, float* rgb_out,
+                        void* stream);
 /* Combine.frag:72-76 without the volume term: rgb = 1 - exp(-exposure * accum / (1 + min(frame_id, 30))).
  * rgb_out: float[3*n]. */
 int gigl_tonemap_device(int device, const float* accum_rgba, uint64_t n, int frame_id, int exposure,

@@ -1286,3 +1286,85 @@ void ora_shade_volume(const ora_fog* fog, const float cam_pos[3], int res_x, int
 }
 
 }  /* extern "C" */
+
+/* ---- Combine.frag (Source/Shaders/Combine.frag:23-77): bilateral upsampling of the half-resolution
+ * volume term, accumulation, normalisation, tone mapping.  PARITY UNPINNED.  Stand-ins: depth_buf =
+ * the GL depth of the primary hit point (lookAt + glm::perspective, Camera.cpp:30-31,
+ * matrix_transform.inl:236-243) quantised to DEPTH_COMPONENT24 (GLTexture2D.h:27), 1.0 where the
+ * primary ray missed; texelFetch outside the image = 0 (robust access); texture(vol_comp) = bilinear,
+ * CLAMP_TO_BORDER with a zero border (GLTexture2D.hpp:22-33). */
+namespace {
+inline float gl_depth24(V3 w_pos, V3 cam, V3 fwd, float t_near, float t_far) {
+    const float z_e = -dot(fwd, w_pos - cam);
+    const float A = -(t_far + t_near) / (t_far - t_near), B = -(2.0f * t_far * t_near) / (t_far - t_near);
+    const float z_ndc = (A * z_e + B) / -z_e;
+    const float d = 0.5f * z_ndc + 0.5f;
+    return floorf(d * 16777215.0f + 0.5f) / 16777215.0f;
+}
+struct C4 { float r, g, b; };
+inline C4 vol_texel(const float* vol, int hw, int hh, int x, int y) {
+    if (x < 0 || x >= hw || y < 0 || y >= hh) return C4{0.0f, 0.0f, 0.0f};
+    const float* p = vol + 4 * ((size_t)x + (size_t)y * hw);
+    return C4{p[0], p[1], p[2]};
+}
+inline C4 vol_bilinear(const float* vol, int hw, int hh, float u, float v) {   /* u, v in texels, centre at +0.5 */
+    const float fu = u - 0.5f, fv = v - 0.5f;
+    const float x0f = floorf(fu), y0f = floorf(fv);
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const float a = fu - x0f, b = fv - y0f;
+    const C4 t00 = vol_texel(vol, hw, hh, x0, y0), t10 = vol_texel(vol, hw, hh, x0 + 1, y0);
+    const C4 t01 = vol_texel(vol, hw, hh, x0, y0 + 1), t11 = vol_texel(vol, hw, hh, x0 + 1, y0 + 1);
+    const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+    return C4{((w00 * t00.r + w10 * t10.r) + w01 * t01.r) + w11 * t11.r,
+              ((w00 * t00.g + w10 * t10.g) + w01 * t01.g) + w11 * t11.g,
+              ((w00 * t00.b + w10 * t10.b) + w01 * t01.b) + w11 * t11.b};
+}
+}  // namespace
+
+extern "C" {
+
+void ora_depth_buffer(const float cam_pos[3], const float cam_dir[3], float t_near, float t_far, const float* po,
+                      const float* pd, const void* prim_hits16, uint64_t n, float* depth) {
+    const Hit16* H = (const Hit16*)prim_hits16;
+    const V3 cam = ld3(cam_pos), fwd = normalize(ld3(cam_dir));
+    for (uint64_t i = 0; i < n; ++i)
+        depth[i] = H[i].tri_id == 0xFFFFFFFFu ? 1.0f
+                                              : gl_depth24(ld3(po + 4 * i) + H[i].t * ld3(pd + 4 * i), cam, fwd, t_near, t_far);
+}
+
+void ora_combine(int res_x, int res_y, const float* depth, const float* vol_comp_rgba, float ext_k, int frame_id,
+                 int exposure, float* accum_rgba, float* rgb) {
+    const int hw = res_x / 2, hh = res_y / 2;
+    std::vector<float> upd;
+    const bool add = frame_id < 30 && ext_k > 0.0f;                              /* :65 */
+    if (add) upd.assign(accum_rgba, accum_rgba + 4 * (size_t)res_x * res_y);
+    const float div = (float)(1 + (frame_id < 30 ? frame_id : 30));
+    for (int y = 0; y < res_y; ++y)
+        for (int x = 0; x < res_x; ++x) {
+            const size_t i = (size_t)x + (size_t)y * res_x;
+            float c[3] = {accum_rgba[4 * i], accum_rgba[4 * i + 1], accum_rgba[4 * i + 2]};
+            if (add) {                                                           /* bilateralUpsampling, :24-49 */
+                const float center_depth = depth[i];
+                float accum_weight = 0.0f, ar = 0.0f, ag = 0.0f, ab = 0.0f;
+                for (int dy = -1; dy <= 1; ++dy)
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        const int px = x + dx, py = y + dy;
+                        const float dpt = (px < 0 || px >= res_x || py < 0 || py >= res_y) ? 0.0f
+                                                                                         : depth[(size_t)px + (size_t)py * res_x];
+                        /* n_pos = vec2(pos) / CAM_RES; in half-resolution texels: pos / 2 */
+                        const C4 col = vol_bilinear(vol_comp_rgba, hw, hh, ((float)px / (float)res_x) * (float)hw,
+                                                    ((float)py / (float)res_y) * (float)hh);
+                        const float weight = (1.0f - 0.3f * (float)abs(dx)) * (1.0f - 0.3f * (float)abs(dy)) /
+                                             (smax(dpt - center_depth, 0.0f) * 1000.0f + 1.0f);
+                        accum_weight += weight;
+                        ar += weight * col.r; ag += weight * col.g; ab += weight * col.b;
+                    }
+                c[0] += ar / accum_weight; c[1] += ag / accum_weight; c[2] += ab / accum_weight;
+                upd[4 * i] = c[0]; upd[4 * i + 1] = c[1]; upd[4 * i + 2] = c[2]; upd[4 * i + 3] = 1.0f;   /* :69 */
+            }
+            for (int k = 0; k < 3; ++k) rgb[3 * i + k] = 1.0f - expf(-(float)exposure * (c[k] / div));     /* :73-75 */
+        }
+    if (add) memcpy(accum_rgba, upd.data(), upd.size() * sizeof(float));
+}
+
+}  /* extern "C" */

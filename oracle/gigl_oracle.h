@@ -163,6 +163,14 @@ void ora_shade_volume(const ora_fog* fog, const float cam_pos[3], int res_x, int
                       float sca_albedo, int gi_enabled, int clamp_rsq, int transm_opt, int frame_id,
                       float* vol_comp_rgba, int n_threads);
 
+/* Combine.frag (Source/Shaders/Combine.frag:23-77).  PARITY UNPINNED; stand-ins at the definition.
+ * depth: float[res_x*res_y] from ora_depth_buffer; accum_rgba in-out; rgb: float[3*res_x*res_y]. */
+void ora_depth_buffer(const float cam_pos[3], const float cam_dir[3], float t_near, float t_far,
+                      const float* prim_o_tmin, const float* prim_d_tmax, const void* prim_hits16,
+                      uint64_t n, float* depth);
+void ora_combine(int res_x, int res_y, const float* depth, const float* vol_comp_rgba, float ext_k,
+                 int frame_id, int exposure, float* accum_rgba, float* rgb);
+
 #ifdef __cplusplus
 }
 #endif

@@ -76,6 +76,8 @@ def lib():
         L.ora_tonemap.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_void_p]
         vp, ci, cf = C.c_void_p, C.c_int, C.c_float
         L.ora_halton2.argtypes = [vp, ci]
+        L.ora_depth_buffer.argtypes = [vp, vp, cf, cf, vp, vp, vp, C.c_uint64, vp]
+        L.ora_combine.argtypes = [ci, ci, vp, vp, cf, ci, ci, vp, vp]
         L.ora_volume_samples.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp]
         L.ora_shadow_points.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint32, vp, ci]
         L.ora_shade_volume.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, ci, vp, C.c_uint32, vp,
@@ -332,3 +334,19 @@ def shade_volume(fog, cam_pos, res_x, res_y, ro, rd, hits, fog_dist, rnd_offsets
                            len(ppls), _p(vpls), len(vpls), _p(occluded), sca_k, sca_albedo, int(gi_enabled),
                            int(clamp_rsq), int(transm_opt), frame_id, _p(out), n_threads)
     return out
+
+
+def depth_buffer(cam_pos, cam_dir, t_near, t_far, ro, rd, hits):
+    ro, rd = _f32(ro).reshape(-1, 4), _f32(rd).reshape(-1, 4)
+    hits = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
+    d = np.zeros(len(ro), np.float32)
+    lib().ora_depth_buffer(_p(_f32(cam_pos)), _p(_f32(cam_dir)), t_near, t_far, _p(ro), _p(rd), _p(hits), len(ro), _p(d))
+    return d
+
+
+def combine(res_x, res_y, depth, vol_comp, ext_k, frame_id, exposure, accum):
+    """Combine.frag (see ora_combine); returns (updated accum, rgb)."""
+    accum = _f32(accum).reshape(-1, 4).copy()
+    rgb = np.zeros((res_x * res_y, 3), np.float32)
+    lib().ora_combine(res_x, res_y, _p(_f32(depth)), _p(_f32(vol_comp)), ext_k, frame_id, exposure, _p(accum), _p(rgb))
+    return accum, rgb

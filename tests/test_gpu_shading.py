@@ -201,5 +201,21 @@ def test_shade_volume_cornell(cornell, oracle_cornell, density, fog_box, gi, tra
     got = vol.cpu().numpy()
     assert (got[:, 3] == 1.0).all() and (want[:, :3].sum(1) > 0).mean() > 0.3
     assert _close(got[:, :3], want[:, :3]), float(np.abs(got[:, :3] - want[:, :3]).max())
+    # ---- Combine.frag: depth stand-in, bilateral upsampling onto the surface pass's buffer, tone mapping ----
+    depth = torch.zeros(n, dtype=torch.float32, device="cuda:0")
+    rt.depth_buffer_device(S.CAM_POS, S.CAM_DIR, 0.1, 2500.0, d_o.data_ptr(), d_d.data_ptr(), d_h.data_ptr(), n,
+                           depth.data_ptr(), stream=sh)
+    acc_before = accum.cpu().numpy()
+    rgb = torch.zeros((n, 3), dtype=torch.float32, device="cuda:0")
+    rt.combine_device(res, res, depth.data_ptr(), vol.data_ptr(), float(ext_k), frame_id, 12, accum.data_ptr(),
+                      rgb.data_ptr(), stream=sh)
+    torch.cuda.synchronize()
+    want_depth = O.depth_buffer(S.CAM_POS, S.CAM_DIR, 0.1, 2500.0, ro, rd, hits)
+    assert np.array_equal(depth.cpu().numpy().view(np.uint32), want_depth.view(np.uint32))
+    assert ((want_depth > 0.99) & (want_depth <= 1.0)).all() and (want_depth == 1.0).any()
+    want_acc, want_rgb = O.combine(res, res, want_depth, got, float(ext_k), frame_id, 12, acc_before)
+    assert _close(accum.cpu().numpy()[:, :3], want_acc[:, :3])
+    assert _close(rgb.cpu().numpy(), want_rgb)
+    assert (want_acc[:, :3] >= acc_before[:, :3]).all() and (want_acc[:, :3] > acc_before[:, :3]).any()
     fog_g.close()
     scene.close()

@@ -113,3 +113,34 @@ def test_shade_volume_properties(cornell, oracle_cornell, density, fog_box):
     assert (dark[:, :3] == 0).all()
     # frame cap (Volume.frag:270)
     assert (O.shade_volume(*args, frame_id=29, **kw)[:, :3].sum() > 0)
+
+
+def test_combine_properties():
+    res, hw = 16, 8
+    rng = np.random.default_rng(4)
+    accum = rng.uniform(0, 1, (res * res, 4)).astype(np.float32)
+    depth = np.full(res * res, 0.5, np.float32)
+    vol = np.zeros((hw * hw, 4), np.float32)
+    vol[:, :3] = [0.25, 0.5, 1.0]
+    acc, rgb = O.combine(res, res, depth, vol, 0.01, 0, 3, accum)
+    # a constant volume term on a constant depth is reproduced exactly away from the zero border
+    inner = np.zeros((res, res), bool)
+    inner[2:-2, 2:-2] = True
+    inner = inner.reshape(-1)
+    assert np.allclose(acc[inner, :3] - accum[inner, :3], [0.25, 0.5, 1.0], rtol=1e-5)
+    assert (acc[~inner, :3] - accum[~inner, :3] <= np.array([0.25, 0.5, 1.0]) * (1 + 1e-5)).all()
+    assert np.allclose(rgb, 1.0 - np.exp(-3.0 * acc[:, :3].astype(np.float64)), rtol=1e-5, atol=1e-6)
+    # no fog or past the last frame: the buffer is left alone, the image is still tone-mapped
+    for ext_k, frame in ((0.0, 0), (0.01, 30)):
+        acc2, rgb2 = O.combine(res, res, depth, vol, ext_k, frame, 3, accum)
+        assert np.array_equal(acc2, accum)
+        assert np.allclose(rgb2, 1.0 - np.exp(-3.0 * accum[:, :3].astype(np.float64) / (1 + min(frame, 30))), rtol=1e-5, atol=1e-6)
+    # a neighbour that lies deeper counts for less (bilateral weight, Combine.frag:41-42)
+    vol2 = np.zeros((hw * hw, 4), np.float32)
+    vol2.reshape(hw, hw, 4)[:, 4:, :3] = 1.0
+    d2 = depth.copy().reshape(res, res)
+    d2[:, 8:] = 0.6
+    flat, _ = O.combine(res, res, depth, vol2, 0.01, 0, 3, np.zeros_like(accum))
+    edge, _ = O.combine(res, res, d2.reshape(-1), vol2, 0.01, 0, 3, np.zeros_like(accum))
+    col = 7   # last column on the near side of the depth step
+    assert (edge.reshape(res, res, 4)[2:-2, col, 0] < flat.reshape(res, res, 4)[2:-2, col, 0]).all()
