@@ -133,6 +133,7 @@ struct TraceParams {
     int refill_thresh;
     int any_atomic;
     unsigned chunk;   // rays a wave takes from the global counter per atomic (multiple of 64)
+    unsigned guided;  // 0: fixed chunks; else requests shrink to remaining / guided near the end
     int t_exit;       // T-phase repeats while at least this many lanes are still descending
     // GEN 0: explicit rays
     const float4* o_tmin;
@@ -151,7 +152,7 @@ struct TraceParams {
     // outputs
     uint4* hits;
     unsigned long long* bits;
-    unsigned long long* stats;   // STATS build only: 8 counters
+    unsigned long long* stats;   // STATS build only: 12 counters
     float2* ranges;              // optional: the ray's (t_min, t_max) as KdTree::intersect leaves them
     const unsigned* perm;        // optional (GEN 0): work item i traces ray perm[i] (ray regrouping)
 };
@@ -349,7 +350,7 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
     int sp = -1;
     bool have_ray = false, pool_empty = false;
     // wave-local slice of the ray index space, refilled CHUNK rays at a time with one atomic
-    unsigned pool_next = 0, pool_end = 0;
+    unsigned pool_next = 0, pool_end = 0, last_base = 0;
     // any-hit "group" mode: a wave owns 64 consecutive rays and writes their bits with one store
     unsigned group_base = kMiss;
     bool occ = false;
@@ -388,6 +389,7 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
     bool need_load = false;
     const int t_exit = P.t_exit;
     // STATS build only: wave-level round counts and lane-level work counts (tools/sweep.py stats=1)
+    const unsigned long long st_t0 = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;
     unsigned st_rounds = 0, st_t_iters = 0, st_t_lanes = 0, st_l_rounds = 0, st_l_lanes = 0, st_refills = 0,
              st_refill_lanes = 0, st_rays_lanes = 0;
 
@@ -404,11 +406,23 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
                 group_base = kMiss;
             }
             if (pool_next == pool_end) {
-                unsigned base = 0;
-                if (lane == 0) base = atomicAdd(P.counter, P.chunk);
+                // Guided self-scheduling: full chunks while plenty of rays remain, smaller ones
+                // (multiples of 64) towards the end, so that the last chunk a wave takes does not
+                // keep it busy long after the others have drained.  The request is sized from the
+                // counter value this wave's previous request returned: stale, but it only sizes
+                // the request (reading the counter with a load instead costs 45 %: the line is
+                // owned by the atomics).
+                unsigned base = 0, take_n = P.chunk;
+                if (P.guided) {
+                    const unsigned rem = last_base < P.n ? P.n - last_base : 0u;
+                    const unsigned g = (rem / P.guided) & ~63u;
+                    take_n = g < 64u ? 64u : (g < P.chunk ? g : P.chunk);
+                }
+                if (lane == 0) base = atomicAdd(P.counter, take_n);
                 base = __builtin_amdgcn_readfirstlane(base);
+                last_base = base;
                 pool_next = base < P.n ? base : P.n;
-                pool_end = (P.n - pool_next) < P.chunk ? P.n : pool_next + P.chunk;
+                pool_end = (P.n - pool_next) < take_n ? P.n : pool_next + take_n;
                 if (pool_next == pool_end) pool_empty = true;
             }
             if (!pool_empty) {
@@ -562,6 +576,13 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
         atomicAdd(P.stats + 5, (unsigned long long)st_refills);
         atomicAdd(P.stats + 6, (unsigned long long)st_refill_lanes);
         atomicAdd(P.stats + 7, (unsigned long long)st_rays_lanes);
+        // when the waves start and stop, on the 100 MHz real-time counter: the drain tail of the
+        // launch is (latest end) - (mean end)
+        const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
+        atomicMax(P.stats + 8, ~st_t0);   // earliest start, complemented (the slot starts at 0)
+        atomicMax(P.stats + 9, t_end);
+        atomicAdd(P.stats + 10, t_end);
+        atomicAdd(P.stats + 11, 1ull);
     }
 }
 
@@ -1243,6 +1264,7 @@ struct Options {
                               // atomicOr; -1: choose by tree depth (deep trees have long-tailed rays)
     int blocks_per_cu = 0;    // 0: occupancy query
     int chunk = 256;          // rays per work-counter atomic
+    int guided = 4;           // 0: fixed chunks; k: near the end a request is remaining / (k * waves)
     int t_exit = 16;          // see trace_kernel: T-phase exit threshold (1..64)
     int stats = 0;            // 1: closest-hit launches run the instrumented build and keep 8 counters
     int sort_rays = 0;        // explicit-ray batches: 1 regroup rays before tracing, 0 never, -1 deep tree + large
@@ -1253,7 +1275,7 @@ struct Options {
 };
 Options g_opt;
 std::mutex g_opt_mu;
-unsigned long long g_last_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+unsigned long long g_last_stats[12] = {0};
 
 constexpr int kBlock = 256;
 constexpr unsigned kMaxRays = 0xF0000000u;
@@ -1333,6 +1355,7 @@ int launch_trace_t(const gigl_scene* s, TraceParams& P, const Options& opt, hipS
     P.counter = (unsigned*)ws;
     P.spill = (uint2*)((char*)ws + 256);
     P.spill_stride = grid * kBlock;
+    P.guided = opt.guided > 0 ? grid * (kBlock / 64u) * (unsigned)opt.guided : 0u;
     P.stats = nullptr;
     if (!ANY && GEN == 0 && STACK_N == 12 && opt.stats) {
         P.stats = (unsigned long long*)((char*)ws + 128);
@@ -1536,10 +1559,10 @@ int gigl_device_count(int* count) {
     return GIGL_OK;
 }
 
-int gigl_debug_last_stats(uint64_t out[8]) {
+int gigl_debug_last_stats(uint64_t out[12]) {
     if (!out) return fail(GIGL_ERR_INVALID, "out is NULL");
     std::lock_guard<std::mutex> lk(g_opt_mu);
-    for (int i = 0; i < 8; ++i) out[i] = g_last_stats[i];
+    for (int i = 0; i < 12; ++i) out[i] = g_last_stats[i];
     return GIGL_OK;
 }
 
@@ -1574,6 +1597,9 @@ int gigl_set_option(const char* name, int value) {
     } else if (k == "chunk") {
         if (value < 64 || value > 65536 || value % 64) return fail(GIGL_ERR_INVALID, "chunk must be a multiple of 64 in 64..65536");
         g_opt.chunk = value;
+    } else if (k == "guided") {
+        if (value < 0 || value > 64) return fail(GIGL_ERR_INVALID, "guided must be in 0..64");
+        g_opt.guided = value;
     } else if (k == "blocks_per_cu") {
         if (value < 0 || value > 8) return fail(GIGL_ERR_INVALID, "blocks_per_cu must be in 0..8");
         g_opt.blocks_per_cu = value;

@@ -130,11 +130,18 @@ def set_option(name, value):
 
 
 def debug_last_stats():
-    out = np.zeros(8, np.uint64)
+    out = np.zeros(12, np.uint64)
     _check(lib().gigl_debug_last_stats(_p(out)))
     names = ["rounds", "t_iters", "t_lane_steps", "l_rounds", "l_lane_rounds", "refills", "refill_lanes",
              "ray_lane_rounds"]
-    return dict(zip(names, out.tolist()))
+    d = dict(zip(names, out[:8].tolist()))
+    waves = int(out[11])
+    if waves:   # wave timing on the 100 MHz real-time counter -> milliseconds since the first wave started
+        t0 = int(~out[8] & np.uint64(0xFFFFFFFFFFFFFFFF))
+        d["waves"] = waves
+        d["last_wave_end_ms"] = (int(out[9]) - t0) / 1e5
+        d["mean_wave_end_ms"] = (int(out[10]) / waves - t0) / 1e5
+    return d
 
 
 def camera_setup(pos, direction, up, h_fov, res_x, res_y):

@@ -234,8 +234,9 @@ int gigl_debug_rescaled_eps(int device, const float* t, uint64_t n, float* out);
 
 /* Scheduling counters of the last closest-hit launch made with option "stats" = 1 (instrumented
  * kernel build; diagnostic only): rounds, T-phase iterations, T lane-steps, L-phase rounds,
- * L lane-rounds, refills, refilled lanes, sum over rounds of lanes holding a ray. */
-int gigl_debug_last_stats(uint64_t out[8]);
+ * L lane-rounds, refills, refilled lanes, sum over rounds of lanes holding a ray; then, on the
+ * 100 MHz real-time counter: ~(earliest wave start), latest wave end, sum of wave ends, waves. */
+int gigl_debug_last_stats(uint64_t out[12]);
 
 /* Tuning knobs (process-wide; read at each launch).  Names and meaning in DESIGN.md. */
 int gigl_set_option(const char* name, int value);

@@ -111,10 +111,11 @@ def test_incoherent_bounce_rays_s16(s16):
     assert np.array_equal(occ.astype(bool), want["tri_id"] != rt.GIGL_MISS)
 
 
-@pytest.mark.parametrize("stack_lds,refill,any_atomic,t_exit,sort_rays,sort_bits",
-                         [(8, 1, 1, 1, 0, 6), (8, 64, 0, 64, 0, 6), (12, 16, 1, 16, 1, 4), (16, 32, 0, 8, 1, 5),
-                          (32, 8, 1, 32, 1, 6), (12, 32, -1, 16, -1, 6)])
-def test_launch_options_do_not_change_results(s16, stack_lds, refill, any_atomic, t_exit, sort_rays, sort_bits):
+@pytest.mark.parametrize("stack_lds,refill,any_atomic,t_exit,sort_rays,sort_bits,guided,chunk",
+                         [(8, 1, 1, 1, 0, 6, 0, 64), (8, 64, 0, 64, 0, 6, 64, 256), (12, 16, 1, 16, 1, 4, 1, 1024),
+                          (16, 32, 0, 8, 1, 5, 4, 128), (32, 8, 1, 32, 1, 6, 8, 256), (12, 32, -1, 16, -1, 6, 4, 256)])
+def test_launch_options_do_not_change_results(s16, stack_lds, refill, any_atomic, t_exit, sort_rays, sort_bits, guided,
+                                              chunk):
     """LDS stack depth (8 forces the global spill path: tree depth 31), refill threshold, T-phase exit
     threshold, the any-hit output mode and ray regrouping are scheduling choices only."""
     ro, rd = synth.bounce_rays(s16["V"], s16["T"], 50_001, 0xABCD01)
@@ -126,6 +127,8 @@ def test_launch_options_do_not_change_results(s16, stack_lds, refill, any_atomic
         rt.set_option("t_exit", t_exit)
         rt.set_option("sort_rays", sort_rays)
         rt.set_option("sort_bits", sort_bits)
+        rt.set_option("guided", guided)
+        rt.set_option("chunk", chunk)
         assert_hits_equal(s16["gpu"].trace(ro, rd), want)
         occ = s16["gpu"].trace(ro, rd, is_vis_ray=True)
         assert np.array_equal(occ.astype(bool), want["tri_id"] != rt.GIGL_MISS)
@@ -136,6 +139,8 @@ def test_launch_options_do_not_change_results(s16, stack_lds, refill, any_atomic
         rt.set_option("t_exit", 16)
         rt.set_option("sort_rays", 0)
         rt.set_option("sort_bits", 6)
+        rt.set_option("guided", 4)
+        rt.set_option("chunk", 256)
 
 
 def test_edge_cases(gpu_cornell, oracle_cornell):
