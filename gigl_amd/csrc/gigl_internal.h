@@ -1,0 +1,326 @@
+// gigl_internal.h — shared by the three translation units of libgigl_rt.so (gigl_rt.hip: traversal,
+// gigl_fog.hip: fog volume kernels, gigl_shade.hip: shading stage).  Device helpers are
+// __forceinline__, so no device symbol crosses a translation unit.
+#pragma once
+#include <hip/hip_runtime.h>
+
+// A/B switches kept from tuning (tools/sweep.py over builds, same device, interleaved): the
+// branch-free child-order predicate is worth 1-3 %; the branch-free triangle test costs 10 VGPRs,
+// drops the kernel from 6 to 5 waves/SIMD and loses 4-10 % on coherent batches.  GIGL_EARLY_PAIR requests
+// both children of a node before the step is decided (+14 % on coherent batches, +1.5 % on the
+// incoherent bench batch, which is bound by the chip's L2-miss rate instead).
+#ifndef GIGL_BRANCHLESS_TRI
+#define GIGL_BRANCHLESS_TRI 0
+#endif
+#ifndef GIGL_BRANCHLESS_STEP
+#define GIGL_BRANCHLESS_STEP 1
+#endif
+#ifndef GIGL_STREAM_HINT
+#define GIGL_STREAM_HINT 1
+#endif
+#ifndef GIGL_EARLY_PAIR
+#define GIGL_EARLY_PAIR 1
+#endif
+
+#include <cfloat>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/gigl_rt.h"
+#include "kd_build.h"
+
+namespace gd {
+
+
+// ------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------
+constexpr float kRayOffset = 1E-4f;              // Source/Common/Constants.h:24
+constexpr float kTriEps = 1E-4f;                 // Constants.h:25
+constexpr unsigned kMiss = 0xFFFFFFFFu;
+constexpr unsigned kLeafBit = 0x80000000u, kLeafPayload = 0x1FFFFFFFu;   // device node word 1, see trace_kernel
+// float4 per flattened triangle record: 4 = one 64-byte line per triangle (a 48-byte record
+// straddles two lines half of the time, and nearly every triangle fetch of an incoherent batch
+// misses L2)
+constexpr unsigned kTriStride = 4;
+
+__device__ __forceinline__ float gmin(float x, float y) { return x < y ? x : y; }
+__device__ __forceinline__ float gmax(float x, float y) { return x > y ? x : y; }
+__device__ __forceinline__ float sel3(unsigned a, float x, float y, float z) { return a == 0u ? x : (a == 1u ? y : z); }
+
+// RTBase.h:18-29: frexp(t,&e); ++e; e >= 0 ? EPS * (1 << e) : EPS / (1 << -e), with `1 << n` evaluated
+// as x86 shl does for the reference (count masked to 5 bits, 1 << 31 = INT_MIN).  frexp's exponent
+// comes from v_frexp_exp_i32_f32 (0 for 0/inf/nan, as glibc).  Every operand is a power of two, so
+// product and quotient are exact and the result is assembled directly: 2^(k-23) or 2^(-23-k),
+// negative when k == 31.  (tests/test_gpu_parity.py::test_rescaled_eps_device checks 8k values
+// against the oracle's literal evaluation.)
+__device__ __forceinline__ float eps_from_exp(int e /* frexp exponent + 1 */) {
+    const unsigned k = (unsigned)(e >= 0 ? e : -e) & 31u;
+    const unsigned ex = e >= 0 ? 104u + k : 104u - k;   // biased exponent of 2^(-23 +/- k)
+    return __uint_as_float((ex << 23) | (k == 31u ? 0x80000000u : 0u));
+}
+__device__ __forceinline__ float rescaled_eps(float t) { return eps_from_exp(__builtin_amdgcn_frexp_expf(t) + 1); }
+// trace_kernel keeps the function as a table in LDS, indexed by frexp exponent + kEpsBias: the
+// exponent of a float (denormals included) lies in [-148, 128].
+constexpr int kEpsBias = 148, kEpsTable = 277;
+
+struct RayReg {
+    float ox, oy, oz, dx, dy, dz, ix, iy, iz, tmin, tmax;
+};
+
+__device__ __forceinline__ void set_dir(RayReg& r, float dx, float dy, float dz) {
+    r.dx = dx; r.dy = dy; r.dz = dz;
+    r.ix = 1.0f / dx; r.iy = 1.0f / dy; r.iz = 1.0f / dz;  // Ray ctor, RTBase.cpp:111-113
+}
+
+struct BoxF { float mnx, mny, mnz, mxx, mxy, mxz; };
+
+// BBox.cpp:81-109
+__device__ __forceinline__ bool box_intersect(const BoxF& b, const RayReg& r, float& entr, float& exit) {
+    const bool sx = r.ix >= 0.0f, sy = r.iy >= 0.0f, sz = r.iz >= 0.0f;
+    float t_entr = ((sx ? b.mnx : b.mxx) - r.ox) * r.ix;
+    float t_exit = ((sx ? b.mxx : b.mnx) - r.ox) * r.ix;
+    const float t_y_min = ((sy ? b.mny : b.mxy) - r.oy) * r.iy;
+    const float t_y_max = ((sy ? b.mxy : b.mny) - r.oy) * r.iy;
+    if ((t_entr > t_y_max) || (t_y_min > t_exit)) return false;
+    t_entr = gmax(t_entr, t_y_min);
+    t_exit = gmin(t_exit, t_y_max);
+    const float t_z_min = ((sz ? b.mnz : b.mxz) - r.oz) * r.iz;
+    const float t_z_max = ((sz ? b.mxz : b.mnz) - r.oz) * r.iz;
+    if ((t_entr > t_z_max) || (t_z_min > t_exit)) return false;
+    t_entr = gmax(t_entr, t_z_min);
+    t_exit = gmin(t_exit, t_z_max);
+    if (t_entr < r.tmax && t_exit > r.tmin) {
+        entr = t_entr; exit = t_exit;
+        return t_entr < FLT_MAX;  // IntDist::operator bool, BBox.cpp:13-15
+    }
+    return false;
+}
+
+struct TraceParams {
+    const uint2* nodes;
+    const unsigned* leaf_ids;
+    const float4* tris;   // kTriStride float4 per triangle: (p0.xyz,e0.x) (e0.yz,e1.xy) (e1.z,mat,-,-) (-)
+    BoxF box;
+    unsigned n;
+    unsigned* counter;
+    uint2* spill;
+    unsigned spill_stride;
+    int refill_thresh;
+    int any_atomic;
+    unsigned chunk;   // rays a wave takes from the global counter per atomic (multiple of 64)
+    unsigned guided;  // 0: fixed chunks; else requests shrink to remaining / guided near the end
+    int t_exit;       // T-phase repeats while at least this many lanes are still descending
+    // GEN 0: explicit rays
+    const float4* o_tmin;
+    const float4* d_tmax;
+    // GEN 1: primary rays
+    float cam[12];
+    unsigned res_x, first;
+    // GEN 2: shadow pairs
+    const float4* prim_o;
+    const float4* prim_d;
+    const uint4* prim_hits;
+    const float* lights;
+    unsigned n_lights;
+    // GEN 3: (point, light) pairs from explicit points (x, y, z, valid)
+    const float4* points;
+    // outputs
+    uint4* hits;
+    unsigned long long* bits;
+    unsigned long long* stats;   // STATS build only: 12 counters
+    float2* ranges;              // optional: the ray's (t_min, t_max) as KdTree::intersect leaves them
+    const unsigned* perm;        // optional (GEN 0): work item i traces ray perm[i] (ray regrouping)
+};
+
+// getPrimaryRay(x + 0.5, y + 0.5), Camera.cpp:65-68; normalize = v * (1/sqrt(dot)) (GLM).
+__device__ __forceinline__ void primary_ray(const float* cam, unsigned res_x, unsigned pix, float& dx, float& dy,
+                                            float& dz) {
+    const float x = (float)(int)(pix % res_x) + 0.5f, y = (float)(int)(pix / res_x) + 0.5f;
+    const float vx = (cam[3] + x * cam[6]) + y * cam[9];
+    const float vy = (cam[4] + x * cam[7]) + y * cam[10];
+    const float vz = (cam[5] + x * cam[8]) + y * cam[11];
+    const float sqr = vx * vx + vy * vy + vz * vz;
+    const float inv = 1.0f / sqrtf(sqr);
+    dx = vx * inv; dy = vy * inv; dz = vz * inv;
+}
+
+struct Cam12 { float c[12]; };
+
+// ---- fog: sampleDensity and the GLSL ray march ----------------------------------------------
+struct FogParams {
+    // Corner bricks: brick (bx,by,bz), bx in [0,rx], holds the 8 texels (x,y,z) with x in
+    // {bx-1, bx}, ... as bytes, byte index = dx + 2*dy + 4*dz, texels outside the volume 0
+    // (DensityField::sample, DensityField.cpp:204-211).  One 8-byte load per trilinear sample.
+    const uint2* bricks;
+    int rx, ry, rz;
+    float mnx, mny, mnz, mxx, mxy, mxz;
+    float ext_k;
+    int n_intervals;
+};
+
+// b / 255.0f (DensityField.cpp:210) without the divide: one Newton correction of b * (1/255) gives
+// the correctly rounded quotient for every byte value (checked exhaustively,
+// tests/test_host_logic.py::test_byte_unorm_is_exact_division).
+__device__ __forceinline__ float byte_unorm(unsigned b) {
+    const float rcp = 1.0f / 255.0f, fb = (float)b;
+    const float r = fb * rcp;
+    return __builtin_fmaf(__builtin_fmaf(-255.0f, r, fb), rcp, r);
+}
+__device__ __forceinline__ float lerp1(float p0, float p1, float t) { return (1.0f - t) * p0 + t * p1; }
+// DensityField.cpp:180-201 from a normalized position; lerp order x, y, z (Interpolation.hpp:8-23)
+__device__ __forceinline__ float fog_filter(const FogParams& F, float nx, float ny, float nz) {
+    const float tcx = nx * (float)F.rx - 0.5f, tcy = ny * (float)F.ry - 0.5f, tcz = nz * (float)F.rz - 0.5f;
+    const float fx = floorf(tcx), fy = floorf(tcy), fz = floorf(tcz);
+    const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+    const float tx = tcx - (float)x0, ty = tcy - (float)y0, tz = tcz - (float)z0;
+    // The reference's upper texel is ceil(tc), which equals x0 when tc is an integer; the brick's
+    // is x0 + 1.  They differ only when the weight t is exactly 0, where (1-0)*a + 0*b = a for
+    // either b, so the filtered value is the same bit for bit.
+    const unsigned bx = (unsigned)x0 + 1u, by = (unsigned)y0 + 1u, bz = (unsigned)z0 + 1u;
+    uint2 w = make_uint2(0u, 0u);   // every texel outside: the lerps still run (inf/NaN weights propagate)
+    if (bx <= (unsigned)F.rx && by <= (unsigned)F.ry && bz <= (unsigned)F.rz)
+        w = F.bricks[bx + (size_t)by * (unsigned)(F.rx + 1) + (size_t)bz * (unsigned)(F.rx + 1) * (unsigned)(F.ry + 1)];
+    const float d000 = byte_unorm(w.x & 0xFFu), d100 = byte_unorm((w.x >> 8) & 0xFFu);
+    const float d010 = byte_unorm((w.x >> 16) & 0xFFu), d110 = byte_unorm(w.x >> 24);
+    const float d001 = byte_unorm(w.y & 0xFFu), d101 = byte_unorm((w.y >> 8) & 0xFFu);
+    const float d011 = byte_unorm((w.y >> 16) & 0xFFu), d111 = byte_unorm(w.y >> 24);
+    const float i0 = lerp1(lerp1(d000, d100, tx), lerp1(d010, d110, tx), ty);
+    const float i1 = lerp1(lerp1(d001, d101, tx), lerp1(d011, d111, tx), ty);
+    return lerp1(i0, i1, tz);
+}
+// GLSL min/max as selects (Surface.frag:146-153)
+__device__ __forceinline__ float smin(float x, float y) { return y < x ? y : x; }
+__device__ __forceinline__ float smax(float x, float y) { return x < y ? y : x; }
+
+// calcTransm + intersectBBox + rayMarch, Surface.frag:139-203
+__device__ __forceinline__ float calc_transm(const FogParams& F, float px, float py, float pz, float wx, float wy,
+                                             float wz, float dist_sq) {
+    if (!(F.ext_k > 0.0f)) return 1.0f;
+    const float max_dist = sqrtf(dist_sq);
+    const float ivx = 1.0f / wx, ivy = 1.0f / wy, ivz = 1.0f / wz;
+    float t0 = (F.mnx - px) * ivx, t1 = (F.mxx - px) * ivx;
+    float t_min = smin(t0, t1), t_max = smax(t0, t1);
+    t0 = (F.mny - py) * ivy; t1 = (F.mxy - py) * ivy;
+    t_min = smax(t_min, smin(t0, t1)); t_max = smin(t_max, smax(t0, t1));
+    t0 = (F.mnz - pz) * ivz; t1 = (F.mxz - pz) * ivz;
+    t_min = smax(t_min, smin(t0, t1)); t_max = smin(t_max, smax(t0, t1));
+    if (!(t_max > smax(t_min, 0.0f) && t_min < max_dist)) return 1.0f;
+    t_min = smax(t_min, 0.0f);
+    t_max = smin(t_max, max_dist);
+    // inv_fog_dims = 1/(max-min), Source/GIGL.cpp:83
+    const float idx = 1.0f / (F.mxx - F.mnx), idy = 1.0f / (F.mxy - F.mny), idz = 1.0f / (F.mxz - F.mnz);
+    const float dt = (t_max - t_min) / (float)F.n_intervals;
+    auto ext_at = [&](float t) {
+        const float qx = px + t * wx, qy = py + t * wy, qz = pz + t * wz;
+        return F.ext_k * fog_filter(F, (qx - F.mnx) * idx, (qy - F.mny) * idy, (qz - F.mnz) * idz);
+    };
+    float prev = ext_at(t_min), total = 0.0f;
+    for (int i = 1; i <= F.n_intervals; ++i) {
+        const float cur = ext_at(t_min + (float)i * dt);
+        total += 0.5f * (prev + cur);
+        prev = cur;
+    }
+    return expf(-(total * dt));
+}
+
+// ---- 3-vectors for the shading stage (operation order as the oracle's V3) ------------------
+struct F3 { float x, y, z; };
+__device__ __forceinline__ F3 f3(float x, float y, float z) { return F3{x, y, z}; }
+__device__ __forceinline__ F3 ld3(const float* p) { return F3{p[0], p[1], p[2]}; }
+__device__ __forceinline__ F3 operator+(F3 a, F3 b) { return F3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ F3 operator-(F3 a, F3 b) { return F3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ F3 operator-(F3 a) { return F3{-a.x, -a.y, -a.z}; }
+__device__ __forceinline__ F3 operator*(F3 a, F3 b) { return F3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+__device__ __forceinline__ F3 operator*(F3 a, float k) { return F3{a.x * k, a.y * k, a.z * k}; }
+__device__ __forceinline__ F3 operator*(float k, F3 a) { return F3{k * a.x, k * a.y, k * a.z}; }
+__device__ __forceinline__ float dot3(F3 a, F3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ float len3(F3 v) { return sqrtf(v.x * v.x + v.y * v.y + v.z * v.z); }
+__device__ __forceinline__ F3 norm3(F3 v) { return v * (1.0f / sqrtf(v.x * v.x + v.y * v.y + v.z * v.z)); }
+__device__ __forceinline__ F3 cross3(F3 a, F3 b) {
+    return F3{a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y};
+}
+
+// ---- host side ------------------------------------------------------------------------------
+int fail(int code, const std::string& msg);   // sets gigl_last_error(); defined in gigl_rt.hip
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice ? GIGL_ERR_NO_DEVICE \
+                                                                              : GIGL_ERR_HIP,      \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                        \
+    } while (0)
+
+constexpr int kBlock = 256;
+constexpr unsigned kMaxRays = 0xF0000000u;
+
+}  // namespace gd
+
+struct gigl_scene {
+    int device = 0;
+    int n_cus = 0;
+    gigl::KdTreeHost tree;
+    uint32_t n_tris = 0;
+    uint2* d_nodes = nullptr;
+    unsigned* d_leaf_ids = nullptr;
+    float4* d_tris = nullptr;
+    gd::BoxF box;
+    gigl_tree_stats stats;
+    // staging for gigl_trace_one
+    float4* d_one = nullptr;   // 2 float4 in, 1 uint4 out
+    std::mutex one_mu;
+};
+
+struct gigl_fog {
+    int device = 0;
+    uint2* d_bricks = nullptr;
+    gd::FogParams fp;
+};
+
+namespace gd {
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+inline unsigned stream_grid(const gigl_scene* s, uint64_t n) {
+    uint64_t g = (n + 255) / 256;
+    const uint64_t cap = (uint64_t)(s ? s->n_cus : 256) * 8;
+    return (unsigned)(g < cap ? (g ? g : 1) : cap);
+}
+
+// Runs a float -> float kernel over host data (diagnostic / convenience entry points).
+inline int map_host(int device, const float* in, size_t in_floats, uint64_t n, float* out,
+                    void (*launch)(const float*, unsigned, float*, const void*), const void* ctx) {
+    DeviceGuard g(device);
+    float *d_in = nullptr, *d_out = nullptr;
+    hipError_t e = hipMalloc((void**)&d_in, in_floats * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_out, n * 4);
+    if (e == hipSuccess) e = hipMemcpy(d_in, in, in_floats * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        launch(d_in, (unsigned)n, d_out, ctx);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(out, d_out, n * 4, hipMemcpyDeviceToHost);
+    if (d_in) (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(GIGL_ERR_HIP, std::string("device map: ") + hipGetErrorString(e));
+    return GIGL_OK;
+}
+
+}  // namespace gd

@@ -22,152 +22,11 @@
 // entries (0.04 % of pushes on the 1M-triangle scene) in a global spill area.
 // Device data layout: flatten_nodes() (pair-addressed nodes in 128-byte treelets) and the 64-byte
 // triangle records built in gigl_scene_create().
-#include <hip/hip_runtime.h>
+#include "gigl_internal.h"
 
-// A/B switches kept from tuning (tools/sweep.py over builds, same device, interleaved): the
-// branch-free child-order predicate is worth 1-3 %; the branch-free triangle test costs 10 VGPRs,
-// drops the kernel from 6 to 5 waves/SIMD and loses 4-10 % on coherent batches.  GIGL_EARLY_PAIR requests
-// both children of a node before the step is decided (+14 % on coherent batches, +1.5 % on the
-// incoherent bench batch, which is bound by the chip's L2-miss rate instead).
-#ifndef GIGL_BRANCHLESS_TRI
-#define GIGL_BRANCHLESS_TRI 0
-#endif
-#ifndef GIGL_BRANCHLESS_STEP
-#define GIGL_BRANCHLESS_STEP 1
-#endif
-#ifndef GIGL_STREAM_HINT
-#define GIGL_STREAM_HINT 1
-#endif
-#ifndef GIGL_EARLY_PAIR
-#define GIGL_EARLY_PAIR 1
-#endif
-
-#include <cfloat>
-#include <chrono>
-#include <cmath>
-#include <cstdio>
-#include <cstring>
-#include <mutex>
-#include <string>
-#include <vector>
-
-#include "../../include/gigl_rt.h"
-#include "kd_build.h"
+using namespace gd;
 
 namespace {
-
-// ------------------------------------------------------------------------------------------
-// device helpers
-// ------------------------------------------------------------------------------------------
-constexpr float kRayOffset = 1E-4f;              // Source/Common/Constants.h:24
-constexpr float kTriEps = 1E-4f;                 // Constants.h:25
-constexpr unsigned kMiss = 0xFFFFFFFFu;
-constexpr unsigned kLeafBit = 0x80000000u, kLeafPayload = 0x1FFFFFFFu;   // device node word 1, see trace_kernel
-// float4 per flattened triangle record: 4 = one 64-byte line per triangle (a 48-byte record
-// straddles two lines half of the time, and nearly every triangle fetch of an incoherent batch
-// misses L2)
-constexpr unsigned kTriStride = 4;
-
-__device__ __forceinline__ float gmin(float x, float y) { return x < y ? x : y; }
-__device__ __forceinline__ float gmax(float x, float y) { return x > y ? x : y; }
-__device__ __forceinline__ float sel3(unsigned a, float x, float y, float z) { return a == 0u ? x : (a == 1u ? y : z); }
-
-// RTBase.h:18-29: frexp(t,&e); ++e; e >= 0 ? EPS * (1 << e) : EPS / (1 << -e), with `1 << n` evaluated
-// as x86 shl does for the reference (count masked to 5 bits, 1 << 31 = INT_MIN).  frexp's exponent
-// comes from v_frexp_exp_i32_f32 (0 for 0/inf/nan, as glibc).  Every operand is a power of two, so
-// product and quotient are exact and the result is assembled directly: 2^(k-23) or 2^(-23-k),
-// negative when k == 31.  (tests/test_gpu_parity.py::test_rescaled_eps_device checks 8k values
-// against the oracle's literal evaluation.)
-__device__ __forceinline__ float eps_from_exp(int e /* frexp exponent + 1 */) {
-    const unsigned k = (unsigned)(e >= 0 ? e : -e) & 31u;
-    const unsigned ex = e >= 0 ? 104u + k : 104u - k;   // biased exponent of 2^(-23 +/- k)
-    return __uint_as_float((ex << 23) | (k == 31u ? 0x80000000u : 0u));
-}
-__device__ __forceinline__ float rescaled_eps(float t) { return eps_from_exp(__builtin_amdgcn_frexp_expf(t) + 1); }
-// trace_kernel keeps the function as a table in LDS, indexed by frexp exponent + kEpsBias: the
-// exponent of a float (denormals included) lies in [-148, 128].
-constexpr int kEpsBias = 148, kEpsTable = 277;
-
-struct RayReg {
-    float ox, oy, oz, dx, dy, dz, ix, iy, iz, tmin, tmax;
-};
-
-__device__ __forceinline__ void set_dir(RayReg& r, float dx, float dy, float dz) {
-    r.dx = dx; r.dy = dy; r.dz = dz;
-    r.ix = 1.0f / dx; r.iy = 1.0f / dy; r.iz = 1.0f / dz;  // Ray ctor, RTBase.cpp:111-113
-}
-
-struct BoxF { float mnx, mny, mnz, mxx, mxy, mxz; };
-
-// BBox.cpp:81-109
-__device__ __forceinline__ bool box_intersect(const BoxF& b, const RayReg& r, float& entr, float& exit) {
-    const bool sx = r.ix >= 0.0f, sy = r.iy >= 0.0f, sz = r.iz >= 0.0f;
-    float t_entr = ((sx ? b.mnx : b.mxx) - r.ox) * r.ix;
-    float t_exit = ((sx ? b.mxx : b.mnx) - r.ox) * r.ix;
-    const float t_y_min = ((sy ? b.mny : b.mxy) - r.oy) * r.iy;
-    const float t_y_max = ((sy ? b.mxy : b.mny) - r.oy) * r.iy;
-    if ((t_entr > t_y_max) || (t_y_min > t_exit)) return false;
-    t_entr = gmax(t_entr, t_y_min);
-    t_exit = gmin(t_exit, t_y_max);
-    const float t_z_min = ((sz ? b.mnz : b.mxz) - r.oz) * r.iz;
-    const float t_z_max = ((sz ? b.mxz : b.mnz) - r.oz) * r.iz;
-    if ((t_entr > t_z_max) || (t_z_min > t_exit)) return false;
-    t_entr = gmax(t_entr, t_z_min);
-    t_exit = gmin(t_exit, t_z_max);
-    if (t_entr < r.tmax && t_exit > r.tmin) {
-        entr = t_entr; exit = t_exit;
-        return t_entr < FLT_MAX;  // IntDist::operator bool, BBox.cpp:13-15
-    }
-    return false;
-}
-
-struct TraceParams {
-    const uint2* nodes;
-    const unsigned* leaf_ids;
-    const float4* tris;   // kTriStride float4 per triangle: (p0.xyz,e0.x) (e0.yz,e1.xy) (e1.z,mat,-,-) (-)
-    BoxF box;
-    unsigned n;
-    unsigned* counter;
-    uint2* spill;
-    unsigned spill_stride;
-    int refill_thresh;
-    int any_atomic;
-    unsigned chunk;   // rays a wave takes from the global counter per atomic (multiple of 64)
-    unsigned guided;  // 0: fixed chunks; else requests shrink to remaining / guided near the end
-    int t_exit;       // T-phase repeats while at least this many lanes are still descending
-    // GEN 0: explicit rays
-    const float4* o_tmin;
-    const float4* d_tmax;
-    // GEN 1: primary rays
-    float cam[12];
-    unsigned res_x, first;
-    // GEN 2: shadow pairs
-    const float4* prim_o;
-    const float4* prim_d;
-    const uint4* prim_hits;
-    const float* lights;
-    unsigned n_lights;
-    // GEN 3: (point, light) pairs from explicit points (x, y, z, valid)
-    const float4* points;
-    // outputs
-    uint4* hits;
-    unsigned long long* bits;
-    unsigned long long* stats;   // STATS build only: 12 counters
-    float2* ranges;              // optional: the ray's (t_min, t_max) as KdTree::intersect leaves them
-    const unsigned* perm;        // optional (GEN 0): work item i traces ray perm[i] (ray regrouping)
-};
-
-// getPrimaryRay(x + 0.5, y + 0.5), Camera.cpp:65-68; normalize = v * (1/sqrt(dot)) (GLM).
-__device__ __forceinline__ void primary_ray(const float* cam, unsigned res_x, unsigned pix, float& dx, float& dy,
-                                            float& dz) {
-    const float x = (float)(int)(pix % res_x) + 0.5f, y = (float)(int)(pix / res_x) + 0.5f;
-    const float vx = (cam[3] + x * cam[6]) + y * cam[9];
-    const float vy = (cam[4] + x * cam[7]) + y * cam[10];
-    const float vz = (cam[5] + x * cam[8]) + y * cam[11];
-    const float sqr = vx * vx + vy * vy + vz * vz;
-    const float inv = 1.0f / sqrtf(sqr);
-    dx = vx * inv; dy = vy * inv; dz = vz * inv;
-}
 
 struct ShadowSeg { float px, py, pz, wx, wy, wz, dist_sq, dist; float nx, ny, nz; };
 
@@ -677,7 +536,6 @@ __global__ void __launch_bounds__(256) ray_scatter_kernel(const unsigned* __rest
 }
 
 // ---- ray generation as its own pass (for callers that want the rays) ----------------------
-struct Cam12 { float c[12]; };
 __global__ void __launch_bounds__(256) primary_rays_kernel(const Cam12 cam, unsigned res_x, unsigned first,
                                                            unsigned n, float4* o_tmin, float4* d_tmax) {
     for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
@@ -685,91 +543,6 @@ __global__ void __launch_bounds__(256) primary_rays_kernel(const Cam12 cam, unsi
         primary_ray(cam.c, res_x, first + i, dx, dy, dz);
         o_tmin[i] = make_float4(cam.c[0], cam.c[1], cam.c[2], 0.0f);
         d_tmax[i] = make_float4(dx, dy, dz, FLT_MAX);
-    }
-}
-
-// ---- fog: sampleDensity and the GLSL ray march ----------------------------------------------
-struct FogParams {
-    // Corner bricks: brick (bx,by,bz), bx in [0,rx], holds the 8 texels (x,y,z) with x in
-    // {bx-1, bx}, ... as bytes, byte index = dx + 2*dy + 4*dz, texels outside the volume 0
-    // (DensityField::sample, DensityField.cpp:204-211).  One 8-byte load per trilinear sample.
-    const uint2* bricks;
-    int rx, ry, rz;
-    float mnx, mny, mnz, mxx, mxy, mxz;
-    float ext_k;
-    int n_intervals;
-};
-
-// b / 255.0f (DensityField.cpp:210) without the divide: one Newton correction of b * (1/255) gives
-// the correctly rounded quotient for every byte value (checked exhaustively,
-// tests/test_host_logic.py::test_byte_unorm_is_exact_division).
-__device__ __forceinline__ float byte_unorm(unsigned b) {
-    const float rcp = 1.0f / 255.0f, fb = (float)b;
-    const float r = fb * rcp;
-    return __builtin_fmaf(__builtin_fmaf(-255.0f, r, fb), rcp, r);
-}
-__device__ __forceinline__ float lerp1(float p0, float p1, float t) { return (1.0f - t) * p0 + t * p1; }
-// DensityField.cpp:180-201 from a normalized position; lerp order x, y, z (Interpolation.hpp:8-23)
-__device__ __forceinline__ float fog_filter(const FogParams& F, float nx, float ny, float nz) {
-    const float tcx = nx * (float)F.rx - 0.5f, tcy = ny * (float)F.ry - 0.5f, tcz = nz * (float)F.rz - 0.5f;
-    const float fx = floorf(tcx), fy = floorf(tcy), fz = floorf(tcz);
-    const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
-    const float tx = tcx - (float)x0, ty = tcy - (float)y0, tz = tcz - (float)z0;
-    // The reference's upper texel is ceil(tc), which equals x0 when tc is an integer; the brick's
-    // is x0 + 1.  They differ only when the weight t is exactly 0, where (1-0)*a + 0*b = a for
-    // either b, so the filtered value is the same bit for bit.
-    const unsigned bx = (unsigned)x0 + 1u, by = (unsigned)y0 + 1u, bz = (unsigned)z0 + 1u;
-    uint2 w = make_uint2(0u, 0u);   // every texel outside: the lerps still run (inf/NaN weights propagate)
-    if (bx <= (unsigned)F.rx && by <= (unsigned)F.ry && bz <= (unsigned)F.rz)
-        w = F.bricks[bx + (size_t)by * (unsigned)(F.rx + 1) + (size_t)bz * (unsigned)(F.rx + 1) * (unsigned)(F.ry + 1)];
-    const float d000 = byte_unorm(w.x & 0xFFu), d100 = byte_unorm((w.x >> 8) & 0xFFu);
-    const float d010 = byte_unorm((w.x >> 16) & 0xFFu), d110 = byte_unorm(w.x >> 24);
-    const float d001 = byte_unorm(w.y & 0xFFu), d101 = byte_unorm((w.y >> 8) & 0xFFu);
-    const float d011 = byte_unorm((w.y >> 16) & 0xFFu), d111 = byte_unorm(w.y >> 24);
-    const float i0 = lerp1(lerp1(d000, d100, tx), lerp1(d010, d110, tx), ty);
-    const float i1 = lerp1(lerp1(d001, d101, tx), lerp1(d011, d111, tx), ty);
-    return lerp1(i0, i1, tz);
-}
-// GLSL min/max as selects (Surface.frag:146-153)
-__device__ __forceinline__ float smin(float x, float y) { return y < x ? y : x; }
-__device__ __forceinline__ float smax(float x, float y) { return x < y ? y : x; }
-
-// calcTransm + intersectBBox + rayMarch, Surface.frag:139-203
-__device__ __forceinline__ float calc_transm(const FogParams& F, float px, float py, float pz, float wx, float wy,
-                                             float wz, float dist_sq) {
-    if (!(F.ext_k > 0.0f)) return 1.0f;
-    const float max_dist = sqrtf(dist_sq);
-    const float ivx = 1.0f / wx, ivy = 1.0f / wy, ivz = 1.0f / wz;
-    float t0 = (F.mnx - px) * ivx, t1 = (F.mxx - px) * ivx;
-    float t_min = smin(t0, t1), t_max = smax(t0, t1);
-    t0 = (F.mny - py) * ivy; t1 = (F.mxy - py) * ivy;
-    t_min = smax(t_min, smin(t0, t1)); t_max = smin(t_max, smax(t0, t1));
-    t0 = (F.mnz - pz) * ivz; t1 = (F.mxz - pz) * ivz;
-    t_min = smax(t_min, smin(t0, t1)); t_max = smin(t_max, smax(t0, t1));
-    if (!(t_max > smax(t_min, 0.0f) && t_min < max_dist)) return 1.0f;
-    t_min = smax(t_min, 0.0f);
-    t_max = smin(t_max, max_dist);
-    // inv_fog_dims = 1/(max-min), Source/GIGL.cpp:83
-    const float idx = 1.0f / (F.mxx - F.mnx), idy = 1.0f / (F.mxy - F.mny), idz = 1.0f / (F.mxz - F.mnz);
-    const float dt = (t_max - t_min) / (float)F.n_intervals;
-    auto ext_at = [&](float t) {
-        const float qx = px + t * wx, qy = py + t * wy, qz = pz + t * wz;
-        return F.ext_k * fog_filter(F, (qx - F.mnx) * idx, (qy - F.mny) * idy, (qz - F.mnz) * idz);
-    };
-    float prev = ext_at(t_min), total = 0.0f;
-    for (int i = 1; i <= F.n_intervals; ++i) {
-        const float cur = ext_at(t_min + (float)i * dt);
-        total += 0.5f * (prev + cur);
-        prev = cur;
-    }
-    return expf(-(total * dt));
-}
-
-__global__ void __launch_bounds__(256) transm_segments_kernel(FogParams F, const float4* seg_p,
-                                                              const float4* seg_d, unsigned n, float* out) {
-    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-        const float4 p = seg_p[i], d = seg_d[i];
-        out[i] = calc_transm(F, p.x, p.y, p.z, d.x, d.y, d.z, d.w);
     }
 }
 
@@ -782,480 +555,24 @@ __global__ void __launch_bounds__(256) transm_shadow_kernel(FogParams F, TracePa
     }
 }
 
-// DensityField::computePiDensity's march (Source/Fog/DensityField.cpp:288-321) for one pixel per
-// lane, after the primary closest-hit pass has produced `hits`.  Stores of one z-plane are
-// coalesced across the lanes of a wave (x fastest).
-__global__ void __launch_bounds__(256) pi_density_kernel(FogParams F, Cam12 cam, unsigned res_x, unsigned n_pix,
-                                                         const uint4* __restrict__ hits, float* __restrict__ out) {
-    const BoxF fb = {F.mnx, F.mny, F.mnz, F.mxx, F.mxy, F.mxz};
-    for (unsigned p = blockIdx.x * 256u + threadIdx.x; p < n_pix; p += gridDim.x * 256u) {
-        RayReg r;
-        float dx, dy, dz;
-        primary_ray(cam.c, res_x, p, dx, dy, dz);
-        r.ox = cam.c[0]; r.oy = cam.c[1]; r.oz = cam.c[2];
-        set_dir(r, dx, dy, dz);
-        r.tmin = 0.0f; r.tmax = FLT_MAX;
-        float entr, exit;
-        if (box_intersect(fb, r, entr, exit)) {
-            const float dist = __uint_as_float(hits[p].y);   // FLT_MAX on a miss, as Ray::Intersection starts
-            const float t_min = gmax(entr, 0.0f), t_max = gmin(exit, dist);
-            const int n_intervals = F.rz * 4;
-            const float dt = (t_max - t_min) / (float)n_intervals;
-            const float ivx = F.mxx - F.mnx, ivy = F.mxy - F.mny, ivz = F.mxz - F.mnz;
-            auto dens_at = [&](float t) {
-                const float qx = r.ox + t * r.dx, qy = r.oy + t * r.dy, qz = r.oz + t * r.dz;
-                return fog_filter(F, (qx - F.mnx) / ivx, (qy - F.mny) / ivy, (qz - F.mnz) / ivz);  // computeNormPos
-            };
-            float prev = dens_at(t_min), dens = 0.0f;
-            for (int i = 1; i <= n_intervals; ++i) {
-                const float cur = dens_at(t_min + (float)i * dt);
-                dens += 0.5f * (cur + prev);
-                prev = cur;
-                if (2 == i % 4) out[p + (size_t)(i / 4) * n_pix] = dens * dt;
-            }
-        } else {
-            for (int z = 0; z < F.rz; ++z) out[p + (size_t)z * n_pix] = 0.0f;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// software shading stage: Surface.frag main() (Source/Shaders/Surface.frag:290-343) and
-// Combine.frag's normalisation + tone mapping (:72-76) as compute kernels over the hit buffers,
-// occlusion bits and transmittance the ray batches produce.  Stand-ins for the GL pipeline are
-// listed in DESIGN.md "Shading stage"; the arithmetic mirrors oracle/gigl_oracle.cpp step by step.
-// ------------------------------------------------------------------------------------------
-struct F3 { float x, y, z; };
-__device__ __forceinline__ F3 f3(float x, float y, float z) { return F3{x, y, z}; }
-__device__ __forceinline__ F3 ld3(const float* p) { return F3{p[0], p[1], p[2]}; }
-__device__ __forceinline__ F3 operator+(F3 a, F3 b) { return F3{a.x + b.x, a.y + b.y, a.z + b.z}; }
-__device__ __forceinline__ F3 operator-(F3 a, F3 b) { return F3{a.x - b.x, a.y - b.y, a.z - b.z}; }
-__device__ __forceinline__ F3 operator-(F3 a) { return F3{-a.x, -a.y, -a.z}; }
-__device__ __forceinline__ F3 operator*(F3 a, F3 b) { return F3{a.x * b.x, a.y * b.y, a.z * b.z}; }
-__device__ __forceinline__ F3 operator*(F3 a, float k) { return F3{a.x * k, a.y * k, a.z * k}; }
-__device__ __forceinline__ F3 operator*(float k, F3 a) { return F3{k * a.x, k * a.y, k * a.z}; }
-__device__ __forceinline__ float dot3(F3 a, F3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
-__device__ __forceinline__ float len3(F3 v) { return sqrtf(v.x * v.x + v.y * v.y + v.z * v.z); }
-__device__ __forceinline__ F3 norm3(F3 v) { return v * (1.0f / sqrtf(v.x * v.x + v.y * v.y + v.z * v.z)); }
-__device__ __forceinline__ F3 cross3(F3 a, F3 b) {
-    return F3{a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y};
-}
-
-// phongBRDF, Surface.frag:205-217
-__device__ __forceinline__ F3 phong_brdf(F3 I, F3 N, F3 O, F3 k_d, F3 k_s, float n_s) {
-    F3 brdf = k_d;
-    if (n_s > 0.0f) {
-        const F3 mI = -I;
-        const F3 S = mI - (2.0f * dot3(N, mI)) * N;   // reflect(-I, N)
-        const float c = dot3(O, S);
-        if (c > 0.0f) brdf = brdf + k_s * powf(c, n_s);
-    }
-    return brdf;
-}
-// evalPhaseHG, Surface.frag:219-223
-__device__ __forceinline__ float phase_hg(float cos_the) {
-    const float g = 0.25f;
-    const float base = 1.0f + g * g - 2.0f * g * cos_the;
-    return 0.25f * 0.318309873f * (1.0f - g * g) / (base * sqrtf(base));
-}
-// computeLe, Surface.frag:225-242.  v: one 96-byte VPL record as 24 words (PointLight.h:66-77)
-__device__ __forceinline__ F3 compute_le(const float* v, F3 O, float sca_albedo) {
-    const unsigned type = __float_as_uint(v[3]);
-    if (type == 1u) return (phase_hg(dot3(O, ld3(v + 8))) * sca_albedo) * ld3(v + 4);
-    if (type == 2u) {
-        const F3 w_norm = ld3(v + 12);
-        const float cos_out = smax(0.0f, dot3(O, w_norm));
-        return (phong_brdf(ld3(v + 8), w_norm, O, ld3(v + 16), ld3(v + 20), v[23]) * ld3(v + 4)) * cos_out;
-    }
-    return f3(0.0f, 0.0f, 0.0f);
-}
-
-struct ShadeParams {
-    float cam[3];
-    unsigned res_x, res_y, first, n_pts, n_ppls, n_vpls;
-    int gi_enabled, clamp_rsq, frame_id, pi_res_z;
-    float sca_albedo;
-    const float4* prim_o;
-    const float4* prim_d;
-    const uint4* hits;
-    const float4* tris;
-    const float* materials;          // 12 floats per material: k_d, pad, k_s, n_s, k_e, pad (RTBase.h:72-77)
-    const float* ppls;               // 8 floats per light: w_pos, pad, intens, pad (std140)
-    const float* vpls;               // 24 words per light
-    const unsigned long long* bits;  // shadow batch occlusion bits, pair = point * n_lights + light
-    const float* transm;             // shadow batch transmittance per pair, or NULL
-    const float* pi_dens;            // computePiDensity's output, or NULL without fog
-    float4* accum;
-    float2* fog_dist;
-};
-
-constexpr int kShadeTile = 16;   // lights per transmittance tile
-
-// One pixel per lane, lights in the reference's order (primary lights, then VPLs).  The pair-major
-// transmittance array is read through a 256 x 16 LDS tile so that the global loads are coalesced.
-__global__ void __launch_bounds__(256) shade_surface_kernel(FogParams F, ShadeParams S) {
-    __shared__ float s_tr[256 * (kShadeTile + 1)];
-    const unsigned tid = threadIdx.x;
-    const unsigned pt0 = blockIdx.x * 256u, pt = pt0 + tid;
-    const unsigned n_lights = S.n_ppls + S.n_vpls;
-    const bool in_range = pt < S.n_pts;
-    F3 col = f3(0.0f, 0.0f, 0.0f);
-    float f_min = 0.0f, f_max = 0.0f, transm_frag = 1.0f;
-    bool lit = false;
-    F3 w_pos = col, N = col, O = col, k_d = col, k_s = col, d = col;
-    float n_s = 0.0f;
-    uint4 h = make_uint4(kMiss, 0u, 0u, 0u);
-    if (in_range) h = S.hits[pt];
-    if (in_range && S.frame_id < 30 && h.x != kMiss) {                       // Surface.frag:292
-        const float4 o4 = S.prim_o[pt], d4 = S.prim_d[pt];
-        d = f3(d4.x, d4.y, d4.z);
-        w_pos = f3(o4.x, o4.y, o4.z) + __uint_as_float(h.y) * d;
-        const F3 cam = f3(S.cam[0], S.cam[1], S.cam[2]);
-        const F3 ray_d = norm3(w_pos - cam);                                 // :296
-        if (F.ext_k > 0.0f) {                                                // :297-315
-            const float t_frag = len3(w_pos - cam);
-            const float ivx = 1.0f / ray_d.x, ivy = 1.0f / ray_d.y, ivz = 1.0f / ray_d.z;
-            float t0 = (F.mnx - cam.x) * ivx, t1 = (F.mxx - cam.x) * ivx;
-            float t_min = smin(t0, t1), t_max = smax(t0, t1);
-            t0 = (F.mny - cam.y) * ivy; t1 = (F.mxy - cam.y) * ivy;
-            t_min = smax(t_min, smin(t0, t1)); t_max = smin(t_max, smax(t0, t1));
-            t0 = (F.mnz - cam.z) * ivz; t1 = (F.mxz - cam.z) * ivz;
-            t_min = smax(t_min, smin(t0, t1)); t_max = smin(t_max, smax(t0, t1));
-            if (t_max > smax(t_min, 0.0f) && t_min < t_frag) {
-                t_min = smax(t_min, 0.0f);
-                t_max = smin(t_max, t_frag);
-                const unsigned pix = S.first + pt;
-                const unsigned px = pix % S.res_x, py = pix / S.res_x;
-                const float z = (t_frag - t_min) / (t_max - t_min);
-                // texture(pi_dens): nearest in x,y, linear in z, CLAMP_TO_EDGE (DensityField.cpp:376-382)
-                float tz = z * (float)S.pi_res_z - 0.5f;
-                tz = smin(smax(tz, 0.0f), (float)(S.pi_res_z - 1));
-                const float fz = floorf(tz);
-                const int z0 = (int)fz, z1 = z0 + 1 < S.pi_res_z ? z0 + 1 : S.pi_res_z - 1;
-                const float f = tz - fz;
-                const size_t plane = (size_t)S.res_x * S.res_y, at = px + (size_t)py * S.res_x;
-                const float a = S.pi_dens[at + (size_t)z0 * plane], b = S.pi_dens[at + (size_t)z1 * plane];
-                const float opt_depth = F.ext_k * ((1.0f - f) * a + f * b);
-                transm_frag = expf(-opt_depth);
-            } else {
-                t_min = t_max = 0.0f;
-            }
-            f_min = t_min; f_max = t_max;
-        }
-        if (transm_frag > 0.001f) {                                           // :316-318
-            lit = true;
-            const float4 ta = S.tris[kTriStride * (size_t)h.x], tb = S.tris[kTriStride * (size_t)h.x + 1];
-            const float4 tc = S.tris[kTriStride * (size_t)h.x + 2];
-            N = norm3(cross3(f3(ta.w, tb.x, tb.y), f3(tb.z, tb.w, tc.x)));
-            if (dot3(d, N) > 0.0f) N = -N;
-            const float* m = S.materials + 12 * (size_t)__float_as_uint(tc.y);
-            k_d = ld3(m); k_s = ld3(m + 4); n_s = m[7];
-            O = -ray_d;
-        }
-    }
-    for (unsigned l0 = 0; l0 < n_lights; l0 += kShadeTile) {
-        if (S.transm) {
-            for (unsigned k = 0; k < (unsigned)kShadeTile; ++k) {
-                const unsigned idx = tid + k * 256u, p = idx / kShadeTile, l = idx % kShadeTile;
-                float v = 1.0f;
-                if (pt0 + p < S.n_pts && l0 + l < n_lights) v = S.transm[(size_t)(pt0 + p) * n_lights + l0 + l];
-                s_tr[p * (kShadeTile + 1) + l] = v;
-            }
-            __syncthreads();
-        }
-        if (lit) {
-            const unsigned l_end = l0 + kShadeTile < n_lights ? l0 + kShadeTile : n_lights;
-            for (unsigned l = l0; l < l_end; ++l) {
-                const bool is_ppl = l < S.n_ppls;
-                if (is_ppl ? !S.clamp_rsq : !S.gi_enabled) continue;                  // :319, :325
-                const size_t pair = (size_t)pt * n_lights + l;
-                if ((S.bits[pair >> 6] >> (pair & 63u)) & 1ull) continue;             // visibility > 0.0
-                const float* v = S.vpls + 24 * (size_t)(is_ppl ? 0u : l - S.n_ppls);
-                const F3 L = is_ppl ? ld3(S.ppls + 8 * l) : ld3(v);
-                const F3 dd = w_pos - L;
-                const float dist_sq = dot3(dd, dd);
-                const F3 I = norm3(-dd);
-                const float tr = S.transm ? s_tr[tid * (kShadeTile + 1) + (l - l0)] : 1.0f;
-                F3 Li;
-                if (is_ppl) {                                                          // :255-258
-                    const float falloff = 1.0f / dist_sq;
-                    Li = (tr * ld3(S.ppls + 8 * l + 4)) * falloff;
-                } else {                                                               // :278-281
-                    const float falloff = 1.0f / smax(dist_sq, 75.0f * 75.0f);
-                    Li = (tr * compute_le(v, -I, S.sca_albedo)) * falloff;
-                }
-                const float cos_inc = smax(0.0f, dot3(I, N));
-                const F3 c = (phong_brdf(I, N, O, k_d, k_s, n_s) * Li) * cos_inc;
-                col = col + transm_frag * c;                                           // :322, :328
-            }
-        }
-        if (S.transm) __syncthreads();
-    }
-    if (in_range && S.frame_id < 30) {
-        if (S.frame_id > 0) {                                                          // :332-337
-            const float4 a = S.accum[pt];
-            col.x += a.x; col.y += a.y; col.z += a.z;
-        }
-        S.accum[pt] = make_float4(col.x, col.y, col.z, 1.0f);                          // :339
-        if (S.fog_dist && F.ext_k > 0.0f) S.fog_dist[pt] = make_float2(f_min, f_max);  // recordRayDist, :314
-    }
-}
-
-// ---- Volume.frag (Source/Shaders/Volume.frag:268-314): half-resolution in-scattering ----------
-struct VolumeParams {
-    float cam[3];
-    unsigned res_x, res_y;            // full resolution (CAM_RES of Surface.frag); this pass runs at res/2
-    unsigned n_samples;               // gi_enabled ? MAX_VOL_SAMP / 4 : MAX_VOL_SAMP
-    unsigned n_ppls, n_vpls;
-    int gi_enabled, clamp_rsq, transm_opt, frame_id, pi_res_z;
-    float sca_k, sca_albedo;
-    const float4* prim_o;             // full-resolution primary rays and hits (the G-buffer stand-in)
-    const float4* prim_d;
-    const uint4* hits;
-    const float2* fog_dist;           // full resolution, written by shade_surface_kernel
-    const float* rnd_offsets;         // res/2 x res/2
-    const float* halton;              // MAX_FRAMES * MAX_VOL_SAMP values
-    const float* pi_dens;
-    const float* ppls;
-    const float* vpls;
-    const unsigned long long* bits;   // pair = (pixel * n_samples + sample) * n_lights + light
-    float4* points;                   // volume_samples_kernel: (s_pos, valid)
-    float4* vol_comp;                 // shade_volume_kernel: rgb, 1
-};
-
-struct VolSample { F3 pos; float transm; bool valid; };
-struct VolPixel { F3 ray_d; float t_min, t_max, z_offset; unsigned tx, ty; bool fog; };
-
-// per-pixel part of main(), Volume.frag:272-282
-__device__ __forceinline__ VolPixel volume_pixel(const VolumeParams& V, unsigned hx, unsigned hy) {
-    VolPixel px;
-    const size_t full = (size_t)(2u * hx + 1u) + (size_t)(2u * hy + 1u) * V.res_x;   // texel (2x+1, 2y+1), :90, :95
-    const float2 fd = V.fog_dist[full];
-    px.t_min = fd.x; px.t_max = fd.y;
-    px.fog = px.t_max > 0.0f && V.frame_id < 30;
-    px.ray_d = f3(0.0f, 0.0f, 0.0f);
-    px.z_offset = 0.0f;
-    // gl_FragCoord.xy / CAM_RES with `#define CAM_RES 1024 / 2` is (xy / 1024) / 2 (Volume.frag:4,
-    // :285): the lookup lands in the lower-left quarter of pi_dens, nearest texel = (hx/2, hy/2)
-    px.tx = hx >> 1; px.ty = hy >> 1;
-    if (px.fog) {
-        const float4 o4 = V.prim_o[full], d4 = V.prim_d[full];
-        const uint4 h = V.hits[full];
-        const F3 w_pos = f3(o4.x, o4.y, o4.z) + __uint_as_float(h.y) * f3(d4.x, d4.y, d4.z);
-        px.ray_d = norm3(w_pos - f3(V.cam[0], V.cam[1], V.cam[2]));
-        px.z_offset = V.rnd_offsets[hx + (size_t)hy * (V.res_x / 2u)];
-    }
-    return px;
-}
-// per-sample part, Volume.frag:285-291
-__device__ __forceinline__ VolSample volume_sample(const FogParams& F, const VolumeParams& V, const VolPixel& px,
-                                                  unsigned s) {
-    VolSample smp;
-    const float hz = V.halton[s + V.n_samples * (unsigned)V.frame_id] + px.z_offset;
-    const float z = smin(smax(hz, 0.0f), 0.995f);                                  // clamp
-    const float t = px.t_min + z * (px.t_max - px.t_min);
-    smp.pos = f3(V.cam[0], V.cam[1], V.cam[2]) + t * px.ray_d;
-    float tz = z * (float)V.pi_res_z - 0.5f;
-    tz = smin(smax(tz, 0.0f), (float)(V.pi_res_z - 1));
-    const float fz = floorf(tz);
-    const int z0 = (int)fz, z1 = z0 + 1 < V.pi_res_z ? z0 + 1 : V.pi_res_z - 1;
-    const float f = tz - fz;
-    const size_t plane = (size_t)V.res_x * V.res_y, at = px.tx + (size_t)px.ty * V.res_x;
-    const float a = V.pi_dens[at + (size_t)z0 * plane], b = V.pi_dens[at + (size_t)z1 * plane];
-    smp.transm = expf(-(F.ext_k * ((1.0f - f) * a + f * b)));
-    smp.valid = smp.transm > 0.001f;                                               // :292
-    return smp;
-}
-
-__global__ void __launch_bounds__(256) volume_samples_kernel(FogParams F, VolumeParams V) {
-    const unsigned hw = V.res_x / 2u, n_pix = hw * (V.res_y / 2u);
-    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n_pix * V.n_samples; i += gridDim.x * 256u) {
-        const unsigned pix = i / V.n_samples, s = i - pix * V.n_samples;
-        const VolPixel px = volume_pixel(V, pix % hw, pix / hw);
-        float4 out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (px.fog) {
-            const VolSample smp = volume_sample(F, V, px, s);
-            if (smp.valid) out = make_float4(smp.pos.x, smp.pos.y, smp.pos.z, 1.0f);
-        }
-        V.points[i] = out;
-    }
-}
-
-// calcTransm of Volume.frag:159-181 (transm_opt: constant medium at the sample point's density)
-__device__ __forceinline__ float calc_transm_vol(const FogParams& F, F3 p, float density, F3 w, float dist_sq,
-                                                 int transm_opt) {
-    if (!transm_opt) return calc_transm(F, p.x, p.y, p.z, w.x, w.y, w.z, dist_sq);
-    if (!(F.ext_k > 0.0f)) return 1.0f;
-    const float max_dist = sqrtf(dist_sq);
-    const float ivx = 1.0f / w.x, ivy = 1.0f / w.y, ivz = 1.0f / w.z;
-    float t0 = (F.mnx - p.x) * ivx, t1 = (F.mxx - p.x) * ivx;
-    float t_min = smin(t0, t1), t_max = smax(t0, t1);
-    t0 = (F.mny - p.y) * ivy; t1 = (F.mxy - p.y) * ivy;
-    t_min = smax(t_min, smin(t0, t1)); t_max = smin(t_max, smax(t0, t1));
-    t0 = (F.mnz - p.z) * ivz; t1 = (F.mxz - p.z) * ivz;
-    t_min = smax(t_min, smin(t0, t1)); t_max = smin(t_max, smax(t0, t1));
-    if (!(t_max > smax(t_min, 0.0f) && t_min < max_dist)) return 1.0f;
-    t_min = smax(t_min, 0.0f);
-    t_max = smin(t_max, max_dist);
-    return expf(-(F.ext_k * density * (t_max - t_min)));
-}
-
-// One half-resolution pixel per lane; samples and lights in the shader's order.
-__global__ void __launch_bounds__(256) shade_volume_kernel(FogParams F, VolumeParams V) {
-    const unsigned hw = V.res_x / 2u, n_pix = hw * (V.res_y / 2u);
-    const unsigned n_lights = V.n_ppls + V.n_vpls;
-    const float idx = 1.0f / (F.mxx - F.mnx), idy = 1.0f / (F.mxy - F.mny), idz = 1.0f / (F.mxz - F.mnz);
-    for (unsigned pix = blockIdx.x * 256u + threadIdx.x; pix < n_pix; pix += gridDim.x * 256u) {
-        const VolPixel px = volume_pixel(V, pix % hw, pix / hw);
-        F3 col = f3(0.0f, 0.0f, 0.0f);
-        if (px.fog) {
-            const F3 O = -px.ray_d;
-            for (unsigned s = 0; s < V.n_samples; ++s) {
-                const VolSample smp = volume_sample(F, V, px, s);
-                if (!smp.valid) continue;
-                // calcFogDens, Volume.frag:121-126
-                const float density = fog_filter(F, (smp.pos.x - F.mnx) * idx, (smp.pos.y - F.mny) * idy,
-                                                 (smp.pos.z - F.mnz) * idz);
-                for (unsigned l = 0; l < n_lights; ++l) {
-                    const bool is_ppl = l < V.n_ppls;
-                    if (is_ppl ? !V.clamp_rsq : !V.gi_enabled) continue;                  // :293, :299
-                    const size_t pair = ((size_t)pix * V.n_samples + s) * n_lights + l;
-                    if ((V.bits[pair >> 6] >> (pair & 63u)) & 1ull) continue;             // visibility > 0.0
-                    const float* v = V.vpls + 24 * (size_t)(is_ppl ? 0u : l - V.n_ppls);
-                    const F3 L = is_ppl ? ld3(V.ppls + 8 * l) : ld3(v);
-                    const F3 dd = smp.pos - L;
-                    const float dist_sq = dot3(dd, dd);
-                    const F3 I = norm3(-dd);
-                    const float tr = calc_transm_vol(F, smp.pos, density, I, dist_sq, V.transm_opt);
-                    F3 Li;
-                    if (is_ppl) Li = (tr * ld3(V.ppls + 8 * l + 4)) * (1.0f / dist_sq);                 // :235-236
-                    else Li = (tr * compute_le(v, -I, V.sca_albedo)) * (1.0f / smax(dist_sq, 75.0f * 75.0f));  // :258-259
-                    const float cos_the = -dot3(I, O);
-                    const F3 c = ((phase_hg(cos_the) * V.sca_k) * density) * Li;                        // :239, :262
-                    col = col + smp.transm * c;                                                          // :296, :302
-                }
-            }
-            col = col * ((px.t_max - px.t_min) / (float)V.n_samples);                                    // :308-309
-        }
-        V.vol_comp[pix] = make_float4(col.x, col.y, col.z, 1.0f);
-    }
-}
-
-// ---- Combine.frag (Source/Shaders/Combine.frag:23-77) --------------------------------------------
-// GL depth of the primary hit point: lookAt + glm::perspective (Camera.cpp:30-31), quantised to
-// DEPTH_COMPONENT24 (GLTexture2D.h:27); 1.0 (the cleared value) where the primary ray missed.
-__global__ void __launch_bounds__(256) depth_kernel(F3 cam, F3 fwd, float t_near, float t_far,
-                                                    const float4* __restrict__ prim_o, const float4* __restrict__ prim_d,
-                                                    const uint4* __restrict__ hits, unsigned n, float* __restrict__ depth) {
-    const float A = -(t_far + t_near) / (t_far - t_near), B = -(2.0f * t_far * t_near) / (t_far - t_near);
-    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-        const uint4 h = hits[i];
-        float d = 1.0f;
-        if (h.x != kMiss) {
-            const float4 o = prim_o[i], dir = prim_d[i];
-            const F3 w_pos = f3(o.x, o.y, o.z) + __uint_as_float(h.y) * f3(dir.x, dir.y, dir.z);
-            const float z_e = -dot3(fwd, w_pos - cam);
-            const float z_ndc = (A * z_e + B) / -z_e;
-            d = floorf((0.5f * z_ndc + 0.5f) * 16777215.0f + 0.5f) / 16777215.0f;
-        }
-        depth[i] = d;
-    }
-}
-
-__device__ __forceinline__ F3 vol_texel(const float4* vol, int hw, int hh, int x, int y) {  // CLAMP_TO_BORDER, border 0
-    if (x < 0 || x >= hw || y < 0 || y >= hh) return f3(0.0f, 0.0f, 0.0f);
-    const float4 t = vol[(size_t)x + (size_t)y * hw];
-    return f3(t.x, t.y, t.z);
-}
-
-__global__ void __launch_bounds__(256) combine_kernel(unsigned res_x, unsigned res_y, const float* __restrict__ depth,
-                                                      const float4* __restrict__ vol, int add, int frame_id,
-                                                      int exposure, float4* accum, float* __restrict__ rgb) {
-    const int hw = (int)(res_x / 2u), hh = (int)(res_y / 2u);
-    const float div = (float)(1 + (frame_id < 30 ? frame_id : 30));
-    const unsigned n = res_x * res_y;
-    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-        const int x = (int)(i % res_x), y = (int)(i / res_x);
-        const float4 a4 = accum[i];
-        F3 c = f3(a4.x, a4.y, a4.z);
-        if (add) {                                       // bilateralUpsampling, :24-49
-            const float center_depth = depth[i];
-            float accum_weight = 0.0f;
-            F3 acc = f3(0.0f, 0.0f, 0.0f);
-            for (int dy = -1; dy <= 1; ++dy)
-                for (int dx = -1; dx <= 1; ++dx) {
-                    const int px = x + dx, py = y + dy;
-                    const bool inside = px >= 0 && px < (int)res_x && py >= 0 && py < (int)res_y;
-                    const float dpt = inside ? depth[(size_t)px + (size_t)py * res_x] : 0.0f;
-                    // texture(vol_comp, vec2(pos) / CAM_RES), bilinear
-                    const float fu = ((float)px / (float)res_x) * (float)hw - 0.5f;
-                    const float fv = ((float)py / (float)res_y) * (float)hh - 0.5f;
-                    const float x0f = floorf(fu), y0f = floorf(fv);
-                    const int x0 = (int)x0f, y0 = (int)y0f;
-                    const float a = fu - x0f, b = fv - y0f;
-                    const F3 t00 = vol_texel(vol, hw, hh, x0, y0), t10 = vol_texel(vol, hw, hh, x0 + 1, y0);
-                    const F3 t01 = vol_texel(vol, hw, hh, x0, y0 + 1), t11 = vol_texel(vol, hw, hh, x0 + 1, y0 + 1);
-                    const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
-                    const F3 col = f3(((w00 * t00.x + w10 * t10.x) + w01 * t01.x) + w11 * t11.x,
-                                      ((w00 * t00.y + w10 * t10.y) + w01 * t01.y) + w11 * t11.y,
-                                      ((w00 * t00.z + w10 * t10.z) + w01 * t01.z) + w11 * t11.z);
-                    const float weight = (1.0f - 0.3f * (float)abs(dx)) * (1.0f - 0.3f * (float)abs(dy)) /
-                                         (smax(dpt - center_depth, 0.0f) * 1000.0f + 1.0f);
-                    accum_weight += weight;
-                    acc = f3(acc.x + weight * col.x, acc.y + weight * col.y, acc.z + weight * col.z);
-                }
-            c = f3(c.x + acc.x / accum_weight, c.y + acc.y / accum_weight, c.z + acc.z / accum_weight);
-            accum[i] = make_float4(c.x, c.y, c.z, 1.0f);                                      // :69
-        }
-        rgb[3 * (size_t)i] = 1.0f - expf(-(float)exposure * (c.x / div));                     // :73-75
-        rgb[3 * (size_t)i + 1] = 1.0f - expf(-(float)exposure * (c.y / div));
-        rgb[3 * (size_t)i + 2] = 1.0f - expf(-(float)exposure * (c.z / div));
-    }
-}
-
-// Combine.frag:72-76 (without the volume term)
-__global__ void __launch_bounds__(256) tonemap_kernel(const float4* __restrict__ accum, unsigned n, int frame_id,
-                                                      int exposure, float* __restrict__ rgb) {
-    const float div = (float)(1 + (frame_id < 30 ? frame_id : 30));
-    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-        const float4 a = accum[i];
-        rgb[3 * (size_t)i] = 1.0f - expf(-(float)exposure * (a.x / div));
-        rgb[3 * (size_t)i + 1] = 1.0f - expf(-(float)exposure * (a.y / div));
-        rgb[3 * (size_t)i + 2] = 1.0f - expf(-(float)exposure * (a.z / div));
-    }
-}
-
-__global__ void __launch_bounds__(256) sample_density_kernel(FogParams F, const float* pos, unsigned n, float* out) {
-    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-        // computeNormPos: (pos - min) / dims, BBox.cpp:53-55
-        const float nx = (pos[3 * i] - F.mnx) / (F.mxx - F.mnx);
-        const float ny = (pos[3 * i + 1] - F.mny) / (F.mxy - F.mny);
-        const float nz = (pos[3 * i + 2] - F.mnz) / (F.mxz - F.mnz);
-        out[i] = fog_filter(F, nx, ny, nz);
-    }
-}
-
 __global__ void __launch_bounds__(256) eps_kernel(const float* t, unsigned n, float* out) {
     for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) out[i] = rescaled_eps(t[i]);
 }
+
+
+}  // namespace
 
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
 thread_local std::string g_err;
 
-int fail(int code, const std::string& msg) {
+int gd::fail(int code, const std::string& msg) {
     g_err = msg;
     return code;
 }
-#define HIP_TRY(expr)                                                                              \
-    do {                                                                                           \
-        hipError_t e_ = (expr);                                                                    \
-        if (e_ != hipSuccess)                                                                      \
-            return fail(e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice ? GIGL_ERR_NO_DEVICE \
-                                                                              : GIGL_ERR_HIP,      \
-                        std::string(#expr) + ": " + hipGetErrorString(e_));                        \
-    } while (0)
+
+namespace {
 
 struct Options {
     int stack_lds = 12;       // LDS entries per lane: 8, 12, 16 or 32
@@ -1276,52 +593,6 @@ struct Options {
 Options g_opt;
 std::mutex g_opt_mu;
 unsigned long long g_last_stats[12] = {0};
-
-constexpr int kBlock = 256;
-constexpr unsigned kMaxRays = 0xF0000000u;
-
-}  // namespace
-
-struct gigl_scene {
-    int device = 0;
-    int n_cus = 0;
-    gigl::KdTreeHost tree;
-    uint32_t n_tris = 0;
-    uint2* d_nodes = nullptr;
-    unsigned* d_leaf_ids = nullptr;
-    float4* d_tris = nullptr;
-    BoxF box;
-    gigl_tree_stats stats;
-    // staging for gigl_trace_one
-    float4* d_one = nullptr;   // 2 float4 in, 1 uint4 out
-    std::mutex one_mu;
-};
-
-struct gigl_fog {
-    int device = 0;
-    uint2* d_bricks = nullptr;
-    FogParams fp;
-};
-
-namespace {
-
-struct DeviceGuard {
-    int prev = -1;
-    bool ok = false;
-    explicit DeviceGuard(int dev) {
-        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-        ok = hipSetDevice(dev) == hipSuccess;
-    }
-    ~DeviceGuard() {
-        if (prev >= 0) (void)hipSetDevice(prev);
-    }
-};
-
-unsigned stream_grid(const gigl_scene* s, uint64_t n) {
-    uint64_t g = (n + 255) / 256;
-    const uint64_t cap = (uint64_t)(s ? s->n_cus : 256) * 8;
-    return (unsigned)(g < cap ? (g ? g : 1) : cap);
-}
 
 template <bool ANY, int GEN, int STACK_N>
 int launch_trace_t(const gigl_scene* s, TraceParams& P, const Options& opt, hipStream_t st) {
@@ -1970,86 +1241,6 @@ int gigl_shadow_batch_device(const gigl_scene* s, const void* prim_o_tmin, const
     return GIGL_OK;
 }
 
-int gigl_shade_surface_device(const gigl_scene* s, const gigl_fog* fog, const gigl_shade_params* prm,
-                              const void* prim_o_tmin, const void* prim_d_tmax, const gigl_hit* prim_hits,
-                              uint64_t n_pts, const float* materials, uint32_t n_materials, const float* ppls,
-                              const void* vpls, const uint64_t* occluded_bits, const float* transm,
-                              const float* pi_dens, float* accum_rgba, float* fog_dist, void* stream) {
-    if (!s || !prm) return fail(GIGL_ERR_INVALID, "scene or params is NULL");
-    if (s->device == GIGL_DEVICE_NONE) return fail(GIGL_ERR_NO_DEVICE, "host-only scene: no device to shade on");
-    if (n_pts == 0) return GIGL_OK;
-    if (!prim_o_tmin || !prim_d_tmax || !prim_hits || !accum_rgba) return fail(GIGL_ERR_INVALID, "NULL input");
-    if (prm->n_ppls < 0 || prm->n_vpls < 0) return fail(GIGL_ERR_INVALID, "negative light count");
-    const uint64_t n_lights = (uint64_t)prm->n_ppls + (uint64_t)prm->n_vpls;
-    if (n_lights > 0 && (!occluded_bits || !materials || n_materials == 0))
-        return fail(GIGL_ERR_INVALID, "lights given without occlusion bits or materials");
-    if ((prm->n_ppls > 0 && !ppls) || (prm->n_vpls > 0 && !vpls)) return fail(GIGL_ERR_INVALID, "NULL light array");
-    if (n_pts > kMaxRays || n_pts * (n_lights ? n_lights : 1) > kMaxRays)
-        return fail(GIGL_ERR_TOO_LARGE, "n_pts * n_lights must stay below 0xF0000000");
-    if (prm->res_x <= 0 || prm->res_y <= 0 || prm->first + n_pts > (uint64_t)prm->res_x * (uint64_t)prm->res_y)
-        return fail(GIGL_ERR_INVALID, "pixel range outside the image");
-    if (fog && fog->device != s->device) return fail(GIGL_ERR_INVALID, "fog and scene live on different devices");
-    if (fog && fog->fp.ext_k > 0.0f && (!pi_dens || prm->pi_res_z <= 0))
-        return fail(GIGL_ERR_INVALID, "fog given without a preintegrated density volume");
-    if (transm && !fog) return fail(GIGL_ERR_INVALID, "transm given without fog");
-    DeviceGuard g(s->device);
-    FogParams F = {};
-    if (fog) F = fog->fp;
-    ShadeParams S = {};
-    for (int a = 0; a < 3; ++a) S.cam[a] = prm->cam_pos[a];
-    S.res_x = (unsigned)prm->res_x; S.res_y = (unsigned)prm->res_y; S.first = (unsigned)prm->first;
-    S.n_pts = (unsigned)n_pts; S.n_ppls = (unsigned)prm->n_ppls; S.n_vpls = (unsigned)prm->n_vpls;
-    S.gi_enabled = prm->gi_enabled; S.clamp_rsq = prm->clamp_rsq; S.frame_id = prm->frame_id;
-    S.pi_res_z = prm->pi_res_z; S.sca_albedo = prm->sca_albedo;
-    S.prim_o = (const float4*)prim_o_tmin; S.prim_d = (const float4*)prim_d_tmax; S.hits = (const uint4*)prim_hits;
-    S.tris = s->d_tris; S.materials = materials; S.ppls = ppls; S.vpls = (const float*)vpls;
-    S.bits = (const unsigned long long*)occluded_bits; S.transm = transm; S.pi_dens = pi_dens;
-    S.accum = (float4*)accum_rgba; S.fog_dist = (float2*)fog_dist;
-    hipLaunchKernelGGL(shade_surface_kernel, dim3((unsigned)((n_pts + 255) / 256)), dim3(256), 0, (hipStream_t)stream, F, S);
-    HIP_TRY(hipGetLastError());
-    return GIGL_OK;
-}
-
-namespace {
-int volume_params(const gigl_scene* s, const gigl_fog* fog, const gigl_shade_params* prm, VolumeParams& V) {
-    if (!s || !fog || !prm) return fail(GIGL_ERR_INVALID, "scene, fog or params is NULL");
-    if (s->device == GIGL_DEVICE_NONE) return fail(GIGL_ERR_NO_DEVICE, "host-only scene: no device to shade on");
-    if (fog->device != s->device) return fail(GIGL_ERR_INVALID, "fog and scene live on different devices");
-    if (prm->res_x < 2 || prm->res_y < 2 || (prm->res_x & 1) || (prm->res_y & 1))
-        return fail(GIGL_ERR_INVALID, "the volume pass needs an even resolution");
-    if ((uint64_t)prm->res_x * (uint64_t)prm->res_y > (1ull << 28)) return fail(GIGL_ERR_TOO_LARGE, "at most 2^28 pixels");
-    if (prm->n_ppls < 0 || prm->n_vpls < 0 || prm->pi_res_z <= 0) return fail(GIGL_ERR_INVALID, "bad light count or pi_res_z");
-    if (prm->frame_id < 0) return fail(GIGL_ERR_INVALID, "negative frame_id");
-    V = VolumeParams{};
-    for (int a = 0; a < 3; ++a) V.cam[a] = prm->cam_pos[a];
-    V.res_x = (unsigned)prm->res_x; V.res_y = (unsigned)prm->res_y;
-    V.n_samples = prm->gi_enabled ? 8u : 32u;       // MAX_VOL_SAMP / 4 : MAX_VOL_SAMP, Volume.frag:277
-    V.n_ppls = (unsigned)prm->n_ppls; V.n_vpls = (unsigned)prm->n_vpls;
-    V.gi_enabled = prm->gi_enabled; V.clamp_rsq = prm->clamp_rsq; V.transm_opt = prm->transm_opt;
-    V.frame_id = prm->frame_id; V.pi_res_z = prm->pi_res_z; V.sca_k = prm->sca_k; V.sca_albedo = prm->sca_albedo;
-    return GIGL_OK;
-}
-}  // namespace
-
-int gigl_volume_samples_device(const gigl_scene* s, const gigl_fog* fog, const gigl_shade_params* prm,
-                               const void* prim_o_tmin, const void* prim_d_tmax, const gigl_hit* prim_hits,
-                               const float* fog_dist, const float* rnd_offsets, const float* halton,
-                               const float* pi_dens, float* points, void* stream) {
-    VolumeParams V;
-    int rc = volume_params(s, fog, prm, V);
-    if (rc != GIGL_OK) return rc;
-    if (!prim_o_tmin || !prim_d_tmax || !prim_hits || !fog_dist || !rnd_offsets || !halton || !pi_dens || !points)
-        return fail(GIGL_ERR_INVALID, "NULL pointer");
-    DeviceGuard g(s->device);
-    V.prim_o = (const float4*)prim_o_tmin; V.prim_d = (const float4*)prim_d_tmax; V.hits = (const uint4*)prim_hits;
-    V.fog_dist = (const float2*)fog_dist; V.rnd_offsets = rnd_offsets; V.halton = halton; V.pi_dens = pi_dens;
-    V.points = (float4*)points;
-    const uint64_t n = (uint64_t)(V.res_x / 2) * (V.res_y / 2) * V.n_samples;
-    hipLaunchKernelGGL(volume_samples_kernel, dim3(stream_grid(s, n)), dim3(256), 0, (hipStream_t)stream, fog->fp, V);
-    HIP_TRY(hipGetLastError());
-    return GIGL_OK;
-}
-
 int gigl_shadow_points_device(const gigl_scene* s, const float* points, uint64_t n_pts, const float* lights,
                               uint32_t n_lights, uint64_t* occluded_bits, void* stream) {
     if (!s) return fail(GIGL_ERR_INVALID, "scene is NULL");
@@ -2068,201 +1259,6 @@ int gigl_shadow_points_device(const gigl_scene* s, const float* points, uint64_t
     return launch_trace<true, 3>(s, P, (hipStream_t)stream);
 }
 
-int gigl_shade_volume_device(const gigl_scene* s, const gigl_fog* fog, const gigl_shade_params* prm,
-                             const void* prim_o_tmin, const void* prim_d_tmax, const gigl_hit* prim_hits,
-                             const float* fog_dist, const float* rnd_offsets, const float* halton,
-                             const float* pi_dens, const float* ppls, const void* vpls,
-                             const uint64_t* occluded_bits, float* vol_comp_rgba, void* stream) {
-    VolumeParams V;
-    int rc = volume_params(s, fog, prm, V);
-    if (rc != GIGL_OK) return rc;
-    if (!prim_o_tmin || !prim_d_tmax || !prim_hits || !fog_dist || !rnd_offsets || !halton || !pi_dens || !vol_comp_rgba)
-        return fail(GIGL_ERR_INVALID, "NULL pointer");
-    if ((V.n_ppls + V.n_vpls) > 0 && !occluded_bits) return fail(GIGL_ERR_INVALID, "lights given without occlusion bits");
-    if ((V.n_ppls > 0 && !ppls) || (V.n_vpls > 0 && !vpls)) return fail(GIGL_ERR_INVALID, "NULL light array");
-    const uint64_t n_pix = (uint64_t)(V.res_x / 2) * (V.res_y / 2);
-    if (n_pix * V.n_samples * (uint64_t)(V.n_ppls + V.n_vpls ? V.n_ppls + V.n_vpls : 1) > kMaxRays)
-        return fail(GIGL_ERR_TOO_LARGE, "pixels * samples * lights must stay below 0xF0000000");
-    DeviceGuard g(s->device);
-    V.prim_o = (const float4*)prim_o_tmin; V.prim_d = (const float4*)prim_d_tmax; V.hits = (const uint4*)prim_hits;
-    V.fog_dist = (const float2*)fog_dist; V.rnd_offsets = rnd_offsets; V.halton = halton; V.pi_dens = pi_dens;
-    V.ppls = ppls; V.vpls = (const float*)vpls; V.bits = (const unsigned long long*)occluded_bits;
-    V.vol_comp = (float4*)vol_comp_rgba;
-    hipLaunchKernelGGL(shade_volume_kernel, dim3(stream_grid(s, n_pix)), dim3(256), 0, (hipStream_t)stream, fog->fp, V);
-    HIP_TRY(hipGetLastError());
-    return GIGL_OK;
-}
-
-int gigl_depth_buffer_device(int device, const float cam_pos[3], const float cam_dir[3], float t_near, float t_far,
-                             const void* prim_o_tmin, const void* prim_d_tmax, const gigl_hit* prim_hits, uint64_t n,
-                             float* depth, void* stream) {
-    if (n == 0) return GIGL_OK;
-    if (!cam_pos || !cam_dir || !prim_o_tmin || !prim_d_tmax || !prim_hits || !depth) return fail(GIGL_ERR_INVALID, "NULL argument");
-    if (n > kMaxRays) return fail(GIGL_ERR_TOO_LARGE, "at most 0xF0000000 pixels per call");
-    if (!(t_far > t_near) || !(t_near > 0.0f)) return fail(GIGL_ERR_INVALID, "need 0 < t_near < t_far");
-    DeviceGuard g(device);
-    if (!g.ok) return fail(GIGL_ERR_NO_DEVICE, "hipSetDevice failed");
-    const float sq = cam_dir[0] * cam_dir[0] + cam_dir[1] * cam_dir[1] + cam_dir[2] * cam_dir[2];
-    const float inv = 1.0f / sqrtf(sq);                      // glm::normalize, on the host as in Camera.cpp:21
-    const F3 fwd = {cam_dir[0] * inv, cam_dir[1] * inv, cam_dir[2] * inv};
-    const F3 cam = {cam_pos[0], cam_pos[1], cam_pos[2]};
-    hipLaunchKernelGGL(depth_kernel, dim3(stream_grid(nullptr, n)), dim3(256), 0, (hipStream_t)stream, cam, fwd, t_near,
-                       t_far, (const float4*)prim_o_tmin, (const float4*)prim_d_tmax, (const uint4*)prim_hits, (unsigned)n,
-                       depth);
-    HIP_TRY(hipGetLastError());
-    return GIGL_OK;
-}
-
-int gigl_combine_device(int device, int res_x, int res_y, const float* depth, const float* vol_comp_rgba, float ext_k,
-                        int frame_id, int exposure, float* accum_rgba, float* rgb_out, void* stream) {
-    if (res_x < 2 || res_y < 2 || (res_x & 1) || (res_y & 1)) return fail(GIGL_ERR_INVALID, "need an even resolution");
-    if ((uint64_t)res_x * (uint64_t)res_y > (1ull << 28)) return fail(GIGL_ERR_TOO_LARGE, "at most 2^28 pixels");
-    if (!accum_rgba || !rgb_out) return fail(GIGL_ERR_INVALID, "NULL argument");
-    const int add = frame_id < 30 && ext_k > 0.0f;                                            // Combine.frag:65
-    if (add && (!depth || !vol_comp_rgba)) return fail(GIGL_ERR_INVALID, "fog on: depth and vol_comp are required");
-    DeviceGuard g(device);
-    if (!g.ok) return fail(GIGL_ERR_NO_DEVICE, "hipSetDevice failed");
-    hipLaunchKernelGGL(combine_kernel, dim3(stream_grid(nullptr, (uint64_t)res_x * res_y)), dim3(256), 0,
-                       (hipStream_t)stream, (unsigned)res_x, (unsigned)res_y, depth, (const float4*)vol_comp_rgba, add,
-                       frame_id, exposure, (float4*)accum_rgba, rgb_out);
-    HIP_TRY(hipGetLastError());
-    return GIGL_OK;
-}
-
-int gigl_tonemap_device(int device, const float* accum_rgba, uint64_t n, int frame_id, int exposure, float* rgb_out,
-                        void* stream) {
-    if (n == 0) return GIGL_OK;
-    if (!accum_rgba || !rgb_out) return fail(GIGL_ERR_INVALID, "NULL argument");
-    if (n > kMaxRays) return fail(GIGL_ERR_TOO_LARGE, "at most 0xF0000000 pixels per call");
-    DeviceGuard g(device);
-    if (!g.ok) return fail(GIGL_ERR_NO_DEVICE, "hipSetDevice failed");
-    hipLaunchKernelGGL(tonemap_kernel, dim3(stream_grid(nullptr, n)), dim3(256), 0, (hipStream_t)stream,
-                       (const float4*)accum_rgba, (unsigned)n, frame_id, exposure, rgb_out);
-    HIP_TRY(hipGetLastError());
-    return GIGL_OK;
-}
-
-int gigl_fog_create(const uint8_t* dens, const int res[3], const float box[6], float ext_k, int n_intervals,
-                    int device, gigl_fog** out) {
-    if (!out) return fail(GIGL_ERR_INVALID, "out is NULL");
-    *out = nullptr;
-    if (!dens || !res || !box) return fail(GIGL_ERR_INVALID, "NULL argument");
-    if (res[0] <= 0 || res[1] <= 0 || res[2] <= 0 || (int64_t)res[0] * res[1] * res[2] > (1ll << 30))
-        return fail(GIGL_ERR_INVALID, "bad volume resolution");
-    if (n_intervals < 1 || n_intervals > 4096) return fail(GIGL_ERR_INVALID, "n_intervals must be in 1..4096");
-    int n_dev = 0;
-    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
-        return fail(GIGL_ERR_NO_DEVICE, "no HIP device: the engine has no CPU fallback");
-    if (device < 0 || device >= n_dev) return fail(GIGL_ERR_INVALID, "device index out of range");
-    DeviceGuard g(device);
-    gigl_fog* f = new gigl_fog();
-    f->device = device;
-    // corner bricks, see FogParams
-    const int rx = res[0], ry = res[1], rz = res[2];
-    std::vector<uint64_t> bricks((size_t)(rx + 1) * (ry + 1) * (rz + 1));
-    auto texel = [&](int x, int y, int z) -> uint64_t {
-        if (x < 0 || x >= rx || y < 0 || y >= ry || z < 0 || z >= rz) return 0;
-        return dens[x + (size_t)y * rx + (size_t)z * rx * ry];
-    };
-    for (int bz = 0; bz <= rz; ++bz)
-        for (int by = 0; by <= ry; ++by)
-            for (int bx = 0; bx <= rx; ++bx) {
-                uint64_t w = 0;
-                for (int c = 0; c < 8; ++c) w |= texel(bx - 1 + (c & 1), by - 1 + ((c >> 1) & 1), bz - 1 + (c >> 2)) << (8 * c);
-                bricks[bx + (size_t)by * (rx + 1) + (size_t)bz * (rx + 1) * (ry + 1)] = w;
-            }
-    const size_t nb = bricks.size() * 8;
-    hipError_t e = hipMalloc((void**)&f->d_bricks, nb);
-    if (e == hipSuccess) e = hipMemcpy(f->d_bricks, bricks.data(), nb, hipMemcpyHostToDevice);
-    if (e != hipSuccess) {
-        if (f->d_bricks) (void)hipFree(f->d_bricks);
-        delete f;
-        return fail(GIGL_ERR_HIP, std::string("fog upload: ") + hipGetErrorString(e));
-    }
-    f->fp = FogParams{f->d_bricks, res[0], res[1], res[2], box[0], box[1], box[2], box[3], box[4], box[5], ext_k,
-                      n_intervals};
-    *out = f;
-    return GIGL_OK;
-}
-
-int gigl_fog_destroy(gigl_fog* f) {
-    if (!f) return GIGL_OK;
-    DeviceGuard g(f->device);
-    (void)hipDeviceSynchronize();
-    (void)hipFree(f->d_bricks);
-    delete f;
-    return GIGL_OK;
-}
-
-int gigl_transmittance_device(const gigl_fog* f, const void* seg_p, const void* seg_d_distsq, uint64_t n,
-                              float* transm, void* stream) {
-    if (!f) return fail(GIGL_ERR_INVALID, "fog is NULL");
-    if (n == 0) return GIGL_OK;
-    if (!seg_p || !seg_d_distsq || !transm) return fail(GIGL_ERR_INVALID, "NULL pointer");
-    if (n > kMaxRays) return fail(GIGL_ERR_TOO_LARGE, "at most 0xF0000000 segments per call");
-    DeviceGuard g(f->device);
-    hipLaunchKernelGGL(transm_segments_kernel, dim3(stream_grid(nullptr, n)), dim3(256), 0, (hipStream_t)stream,
-                       f->fp, (const float4*)seg_p, (const float4*)seg_d_distsq, (unsigned)n, transm);
-    HIP_TRY(hipGetLastError());
-    return GIGL_OK;
-}
-
-static int map_host(int device, const float* in, size_t in_floats, uint64_t n, float* out,
-                    void (*launch)(const float*, unsigned, float*, const void*), const void* ctx) {
-    DeviceGuard g(device);
-    float *d_in = nullptr, *d_out = nullptr;
-    hipError_t e = hipMalloc((void**)&d_in, in_floats * 4);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_out, n * 4);
-    if (e == hipSuccess) e = hipMemcpy(d_in, in, in_floats * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess) {
-        launch(d_in, (unsigned)n, d_out, ctx);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipDeviceSynchronize();
-    if (e == hipSuccess) e = hipMemcpy(out, d_out, n * 4, hipMemcpyDeviceToHost);
-    if (d_in) (void)hipFree(d_in);
-    if (d_out) (void)hipFree(d_out);
-    if (e != hipSuccess) return fail(GIGL_ERR_HIP, std::string("device map: ") + hipGetErrorString(e));
-    return GIGL_OK;
-}
-
-int gigl_compute_pi_density_device(const gigl_scene* s, const gigl_fog* f, const float cam[12], int res_x,
-                                   int res_y, float* pi_dens, void* stream) {
-    if (!s || !f || !cam || res_x <= 0 || res_y <= 0) return fail(GIGL_ERR_INVALID, "bad argument");
-    if (s->device == GIGL_DEVICE_NONE) return fail(GIGL_ERR_NO_DEVICE, "host-only scene: no device to trace on");
-    if (f->device != s->device) return fail(GIGL_ERR_INVALID, "fog and scene live on different devices");
-    if (!pi_dens) return fail(GIGL_ERR_INVALID, "NULL output");
-    const uint64_t n = (uint64_t)res_x * (uint64_t)res_y;
-    if (n > (1ull << 28)) return fail(GIGL_ERR_TOO_LARGE, "at most 2^28 pixels per call");
-    DeviceGuard g(s->device);
-    hipStream_t st = (hipStream_t)stream;
-    void* hits = nullptr;
-    HIP_TRY(hipMallocAsync(&hits, n * sizeof(gigl_hit), st));
-    int rc = gigl_trace_primary_device(s, cam, res_x, 0, n, (gigl_hit*)hits, stream);
-    if (rc == GIGL_OK) {
-        Cam12 c;
-        memcpy(c.c, cam, sizeof(c.c));
-        hipLaunchKernelGGL(pi_density_kernel, dim3(stream_grid(s, n)), dim3(256), 0, st, f->fp, c, (unsigned)res_x,
-                           (unsigned)n, (const uint4*)hits, pi_dens);
-        if (hipGetLastError() != hipSuccess) rc = fail(GIGL_ERR_HIP, "pi_density_kernel launch failed");
-    }
-    if (hipFreeAsync(hits, st) != hipSuccess && rc == GIGL_OK) rc = fail(GIGL_ERR_HIP, "hipFreeAsync");
-    return rc;
-}
-
-int gigl_sample_density(const gigl_fog* f, const float* pos, uint64_t n, float* dens_out) {
-    if (!f) return fail(GIGL_ERR_INVALID, "fog is NULL");
-    if (n == 0) return GIGL_OK;
-    if (!pos || !dens_out) return fail(GIGL_ERR_INVALID, "NULL pointer");
-    if (n > (1u << 28)) return fail(GIGL_ERR_TOO_LARGE, "at most 2^28 positions per call");
-    return map_host(f->device, pos, 3 * n, n, dens_out,
-                    [](const float* in, unsigned m, float* o, const void* ctx) {
-                        hipLaunchKernelGGL(sample_density_kernel, dim3((m + 255) / 256), dim3(256), 0, nullptr,
-                                           *(const FogParams*)ctx, in, m, o);
-                    },
-                    &f->fp);
-}
-
 int gigl_debug_rescaled_eps(int device, const float* t, uint64_t n, float* out) {
     if (n == 0) return GIGL_OK;
     if (!t || !out) return fail(GIGL_ERR_INVALID, "NULL pointer");
@@ -2279,3 +1275,4 @@ int gigl_debug_rescaled_eps(int device, const float* t, uint64_t n, float* out) 
 }
 
 }  // extern "C"
+

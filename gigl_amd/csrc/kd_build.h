@@ -3,7 +3,7 @@
 // Produces exactly the tree rt::KdTree<Triangle> builds in the reference
 // (/root/reference/Source/RT/KdTree.hpp:87-264): same split choices, same leaf contents and
 // order, same DFS node numbering, in the reference's 8-byte node encoding
-// (Source/RT/KdTree.h:22-65).  The flattened device layout is derived from it in gigl_rt.hip.
+// (Source/RT/KdTree.h:22-65).  The flattened device layout is derived from it in gigl_rt.hip (flatten_nodes).
 #pragma once
 #include <cstdint>
 #include <vector>

@@ -176,7 +176,7 @@ def _round_f32(x):
 
 def test_byte_unorm_is_exact_division():
     """The fog kernels turn a density byte into b / 255.0f (DensityField.cpp:210) with one multiply
-    and two fused multiply-adds (byte_unorm in gigl_rt.hip); every byte value must give the
+    and two fused multiply-adds (byte_unorm in gigl_internal.h); every byte value must give the
     correctly rounded quotient, evaluated here in exact rational arithmetic."""
     from fractions import Fraction
     rcp = _round_f32(Fraction(1, 255))
