@@ -247,6 +247,19 @@ def extras(torch, rt, S, scene, d_o, d_d, n, device):
     bits = torch.zeros((n + 63) // 64, dtype=torch.int64, device=device)
     ms = timeit(lambda: scene.trace_any_device(d_o.data_ptr(), d_d.data_ptr(), n, bits.data_ptr(), sh))
     res["any_hit_same_batch_mrays_s"] = round(n / ms / 1e3, 2)
+    # the same closest-hit step issued alternately on two streams: the drain of one launch (9 % of
+    # it) overlaps the start of the next, as batches of a running renderer would
+    two = [torch.cuda.Stream(device=device) for _ in range(2)]
+    h2 = [torch.empty((n, 4), dtype=torch.int32, device=device) for _ in range(2)]
+    for reps in (2, 10):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(reps):
+            scene.trace_closest_device(d_o.data_ptr(), d_d.data_ptr(), n, h2[i % 2].data_ptr(), two[i % 2].cuda_stream)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+    res["closest_hit_two_streams_mrays_s"] = round(n / dt / 1e6, 2)
+    del h2
     # Cornell: 1024^2 primary + x150 shadow (+ transmittance)
     cv, ct, _, _ = S.load_obj(os.path.join(ROOT, "tests", "golden", "cornell_box.obj"))
     cs = rt.Scene(cv, ct, device=device.index, **S.KD_PARAMS)
