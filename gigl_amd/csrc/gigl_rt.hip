@@ -626,7 +626,10 @@ int launch_trace_t(const gigl_scene* s, TraceParams& P, const Options& opt, hipS
     P.counter = (unsigned*)ws;
     P.spill = (uint2*)((char*)ws + 256);
     P.spill_stride = grid * kBlock;
+    // guided requests only for batches that are long against the machine: a small batch would run
+    // on minimum-size requests from its first ray (one atomic round trip per refill)
     P.guided = opt.guided > 0 ? grid * (kBlock / 64u) * (unsigned)opt.guided : 0u;
+    if ((uint64_t)P.n < 2ull * P.guided * P.chunk) P.guided = 0u;
     P.stats = nullptr;
     if (!ANY && GEN == 0 && STACK_N == 12 && opt.stats) {
         P.stats = (unsigned long long*)((char*)ws + 128);
