@@ -23,6 +23,7 @@
 // Device data layout: flatten_nodes() (pair-addressed nodes in 128-byte treelets) and the 64-byte
 // triangle records built in gigl_scene_create().
 #include "gigl_internal.h"
+#include "kd_layout.h"
 
 using namespace gd;
 
@@ -589,6 +590,8 @@ struct Options {
                               // cost more than the 1.7 ms the regrouped traversal saves
     int sort_bits = 6;        // cells per axis = 2^sort_bits (4..6)
     int treelet_levels = 3;   // read at gigl_scene_create: levels of child pairs per cache-line treelet (1..5)
+    int layout = 1;           // read at gigl_scene_create: 0 level treelets + separate id lists, 1 clustered lines
+                              // with the id lists in their leaves' lines (kd_layout.h)
 };
 Options g_opt;
 std::mutex g_opt_mu;
@@ -655,7 +658,7 @@ int launch_trace(const gigl_scene* s, TraceParams& P, hipStream_t st) {
         opt = g_opt;
     }
     P.nodes = s->d_nodes;
-    P.leaf_ids = s->d_leaf_ids;
+    P.leaf_ids = s->d_leaf_ids ? s->d_leaf_ids : reinterpret_cast<const unsigned*>(s->d_nodes);  // clustered: lists in the node buffer
     P.tris = s->d_tris;
     P.box = s->box;
     P.any_atomic = ANY ? (opt.any_atomic < 0 ? (s->tree.actual_depth > 20 ? 1 : 0) : opt.any_atomic) : 0;
@@ -730,93 +733,6 @@ int check_batch(const gigl_scene* s, const void* a, const void* b, uint64_t n, c
 
 }  // namespace
 
-namespace {
-
-// Re-encodes one host node for the device (see trace_kernel): leaves get a kind field and 2-prim
-// leaves carry their ids inline; interior nodes get the index of their children PAIR.
-inline gigl::KdNode device_leaf(const gigl::KdTreeHost& T, const gigl::KdNode& h) {
-    gigl::KdNode nd = h;
-    const uint32_t np = h.w1 >> 1;
-    if (np == 0) { nd.w0 = 0; nd.w1 = kLeafBit; }
-    else if (np == 1) nd.w1 = kLeafBit | (1u << 29);
-    else if (np == 2) {
-        nd.w0 = T.leaf_prim_ids[h.w0];
-        nd.w1 = kLeafBit | (2u << 29) | T.leaf_prim_ids[h.w0 + 1];
-    } else nd.w1 = kLeafBit | (3u << 29) | np;
-    return nd;
-}
-
-// Device node order.  The reference numbers nodes depth-first (bottom child = parent + 1,
-// KdTree.hpp:254-262), which makes every step to a top child a jump to a far cache line.  Here the
-// two children of a node sit side by side (one 16-byte pair; the parent stores the pair index) and
-// pairs are laid out in treelets: a breadth-first walk of `levels` levels of pairs below a treelet
-// root (1 + 2 + 4 = 7 pairs = 112 B for 3 levels) is stored contiguously and never straddles a
-// 128-byte line, so up to three consecutive steps of a ray read one line.  Topology, leaf contents
-// and traversal order are untouched; only addresses change.  Slot 0 is the root, slot 1 padding.
-void flatten_nodes(const gigl::KdTreeHost& T, int levels, std::vector<gigl::KdNode>& out) {
-    out.clear();
-    const std::vector<gigl::KdNode>& H = T.nodes;
-    if (H.empty()) {  // empty scene: a single empty leaf (KdTree.hpp:9-12)
-        out.push_back(gigl::KdNode{0u, kLeafBit});
-        out.push_back(gigl::KdNode{0u, kLeafBit});
-        return;
-    }
-    out.reserve(H.size() + H.size() / 4 + 16);
-    out.resize(2, gigl::KdNode{0u, kLeafBit});
-    const unsigned max_pairs = (1u << levels) - 1u;           // pairs in a full treelet
-    const unsigned line_pairs = 8;                            // 128 B / 16 B
-    struct Item { uint32_t host; uint32_t slot; };            // interior host node, its device slot
-    std::vector<Item> roots, cur, nxt;
-    if (H[0].w1 & 1u) { out[0] = device_leaf(T, H[0]); return; }
-    out[0] = gigl::KdNode{H[0].w0, (H[0].w1 >> 1) & 3u};
-    roots.push_back(Item{0u, 0u});
-    while (!roots.empty()) {
-        const Item r = roots.back();
-        roots.pop_back();
-        // first pass: how many pairs will this treelet hold?
-        unsigned n_pairs = 0;
-        cur.assign(1, r);
-        for (int lv = 0; lv < levels && !cur.empty(); ++lv) {
-            nxt.clear();
-            for (const Item& it : cur) {
-                ++n_pairs;
-                const uint32_t kids[2] = {it.host + 1u, H[it.host].w1 >> 3};
-                for (uint32_t k : kids)
-                    if (!(H[k].w1 & 1u)) nxt.push_back(Item{k, 0u});
-            }
-            cur.swap(nxt);
-        }
-        size_t pos = out.size() / 2;                           // in pairs
-        if (max_pairs <= line_pairs && (pos % line_pairs) + n_pairs > line_pairs)
-            pos = (pos + line_pairs - 1) / line_pairs * line_pairs;
-        out.resize(2 * pos, gigl::KdNode{0u, kLeafBit});
-        // second pass: emit breadth-first
-        cur.assign(1, r);
-        std::vector<Item> frontier;
-        for (int lv = 0; lv < levels && !cur.empty(); ++lv) {
-            nxt.clear();
-            for (const Item& it : cur) {
-                const uint32_t pair = (uint32_t)(out.size() / 2);
-                out[it.slot].w1 = (out[it.slot].w1 & 3u) | ((uint32_t)(2 * pair) << 2);
-                const uint32_t kids[2] = {it.host + 1u, H[it.host].w1 >> 3};
-                for (uint32_t k : kids) {
-                    const uint32_t slot = (uint32_t)out.size();
-                    if (H[k].w1 & 1u) out.push_back(device_leaf(T, H[k]));
-                    else {
-                        out.push_back(gigl::KdNode{H[k].w0, (H[k].w1 >> 1) & 3u});
-                        (lv + 1 < levels ? nxt : frontier).push_back(Item{k, slot});
-                    }
-                }
-            }
-            cur.swap(nxt);
-        }
-        // deeper treelets of this subtree follow it closely (depth-first over treelets)
-        for (size_t i = frontier.size(); i-- > 0;) roots.push_back(frontier[i]);
-    }
-}
-
-}  // namespace
-
 extern "C" {
 
 const char* gigl_last_error(void) { return g_err.c_str(); }
@@ -830,6 +746,18 @@ int gigl_device_count(int* count) {
         return fail(GIGL_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
     }
     *count = n;
+    return GIGL_OK;
+}
+
+int gigl_debug_check_layout(const gigl_scene* s, int layout, int treelet_levels, uint64_t* bytes_out) {
+    if (!s) return fail(GIGL_ERR_INVALID, "scene is NULL");
+    if (layout < 0 || layout > 1 || treelet_levels < 1 || treelet_levels > 5) return fail(GIGL_ERR_INVALID, "bad layout");
+    gigl::DeviceTree dt;
+    if (layout == 1) gigl::layout_clustered(s->tree, dt);
+    else gigl::layout_levels(s->tree, treelet_levels, dt);
+    const char* what = nullptr;
+    if (!gigl::layout_verify(s->tree, dt, &what)) return fail(GIGL_ERR_BUILD, std::string("device layout differs from the host tree: ") + (what ? what : "?"));
+    if (bytes_out) *bytes_out = dt.slots.size() * 8 + (dt.ids_inline ? 0 : s->tree.leaf_prim_ids.size() * 4);
     return GIGL_OK;
 }
 
@@ -860,6 +788,9 @@ int gigl_set_option(const char* name, int value) {
     } else if (k == "treelet_levels") {
         if (value < 1 || value > 5) return fail(GIGL_ERR_INVALID, "treelet_levels must be in 1..5");
         g_opt.treelet_levels = value;
+    } else if (k == "layout") {
+        if (value < 0 || value > 1) return fail(GIGL_ERR_INVALID, "layout must be 0 or 1");
+        g_opt.layout = value;
     } else if (k == "sort_bits") {
         if (value < 4 || value > 6) return fail(GIGL_ERR_INVALID, "sort_bits must be in 4..6");
         g_opt.sort_bits = value;
@@ -897,10 +828,11 @@ int gigl_scene_create(const float* verts, uint32_t n_verts, const uint32_t* tris
         if (device < 0 || device >= n_dev) return fail(GIGL_ERR_INVALID, "device index out of range");
     }
 
-    int treelet_levels;
+    int treelet_levels, layout;
     {
         std::lock_guard<std::mutex> lk(g_opt_mu);
         treelet_levels = g_opt.treelet_levels;
+        layout = g_opt.layout;
     }
     gigl_scene* s = new gigl_scene();
     s->device = device;
@@ -958,15 +890,18 @@ int gigl_scene_create(const float* verts, uint32_t n_verts, const uint32_t* tris
         (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr);
     }
     // ---- device node array: same topology, cache-line treelet order (see flatten_nodes) ----
-    std::vector<gigl::KdNode> dn;
-    flatten_nodes(s->tree, treelet_levels, dn);
+    gigl::DeviceTree dtree;
+    if (layout == 1) gigl::layout_clustered(s->tree, dtree);
+    else gigl::layout_levels(s->tree, treelet_levels, dtree);
+    const std::vector<gigl::KdNode>& dn = dtree.slots;
+    const bool ids_inline = dtree.ids_inline;
     // device node word 1 keeps 29 bits for a triangle id / leaf size and 29 for a node slot
     if (n_tris > kLeafPayload || dn.size() >= (1u << 29) || s->tree.leaf_prim_ids.size() > kLeafPayload) {
         delete s;
         return fail(GIGL_ERR_TOO_LARGE, "scene exceeds the device node encoding (2^29 triangles / node slots)");
     }
     const size_t nb_nodes = std::max<size_t>(dn.size(), 2) * sizeof(uint2);
-    const size_t nb_leaf = std::max<size_t>(s->tree.leaf_prim_ids.size(), 1) * 4;
+    const size_t nb_leaf = ids_inline ? 0 : std::max<size_t>(s->tree.leaf_prim_ids.size(), 1) * 4;
     const size_t nb_tris = std::max<size_t>(rec.size(), 16) * 4;
     auto cleanup = [&]() {
         if (s->d_nodes) (void)hipFree(s->d_nodes);
@@ -984,11 +919,11 @@ int gigl_scene_create(const float* verts, uint32_t n_verts, const uint32_t* tris
         }                                                                                     \
     } while (0)
     CREATE_TRY(hipMalloc((void**)&s->d_nodes, nb_nodes));
-    CREATE_TRY(hipMalloc((void**)&s->d_leaf_ids, nb_leaf));
+    if (!ids_inline) CREATE_TRY(hipMalloc((void**)&s->d_leaf_ids, nb_leaf));
     CREATE_TRY(hipMalloc((void**)&s->d_tris, nb_tris));
     CREATE_TRY(hipMalloc((void**)&s->d_one, 64));
     CREATE_TRY(hipMemcpy(s->d_nodes, dn.data(), dn.size() * 8, hipMemcpyHostToDevice));
-    if (!s->tree.leaf_prim_ids.empty())
+    if (!ids_inline && !s->tree.leaf_prim_ids.empty())
         CREATE_TRY(hipMemcpy(s->d_leaf_ids, s->tree.leaf_prim_ids.data(), s->tree.leaf_prim_ids.size() * 4,
                              hipMemcpyHostToDevice));
     if (!rec.empty()) CREATE_TRY(hipMemcpy(s->d_tris, rec.data(), rec.size() * 4, hipMemcpyHostToDevice));

@@ -1,0 +1,45 @@
+// Device layout of the k-d tree (product code, host side).
+//
+// The tree built by kd_build() keeps the reference's encoding and depth-first numbering
+// (/root/reference/Source/RT/KdTree.h:22-65, KdTree.hpp:254-262).  The traversal kernel reads a
+// re-addressed copy: same topology, same leaf contents in the same order, different addresses.
+// Two layouts are provided; both use the device node encoding documented at trace_kernel:
+//   interior: w0 = split_pos, w1 = slot of the children pair << 2 | axis (bottom child first)
+//   leaf:     w1 bit 31 = 1, bits 29-30 = kind, bits 0-28 = payload
+//             kind 0 empty | 1 one prim (w0 = id) | 2 two prims (w0 = id0, payload = id1)
+//             kind 3: n >= 3 prims, payload = n, w0 = index of the id list in 4-byte units
+//                     (into leaf_prim_ids for the level layout, into the node buffer itself for
+//                     the clustered layout, which keeps the list in the leaf's own cache line)
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "kd_build.h"
+
+namespace gigl {
+
+constexpr uint32_t kDevLeafBit = 0x80000000u, kDevLeafPayload = 0x1FFFFFFFu;
+
+struct DeviceTree {
+    std::vector<KdNode> slots;          // 8-byte slots: nodes (and, clustered layout, inline id lists)
+    bool ids_inline = false;            // kind-3 leaves index `slots` (as uint32) instead of leaf_prim_ids
+    // optional diagnostics (filled when non-null on entry): device slot of every host node
+    std::vector<uint32_t>* slot_of_host = nullptr;
+};
+
+// Level layout: treelets of `levels` breadth-first levels of child pairs that never straddle a
+// 128-byte line (round-1 layout).
+void layout_levels(const KdTreeHost& T, int levels, DeviceTree& out);
+
+// Clustered layout: every 128-byte line is filled greedily from a cluster root with the child pairs
+// most likely to be read next (largest cell surface area first, the probability a random line that
+// crosses the parent's cell crosses the child's), together with the id lists of the leaves it
+// holds.  Subtrees that fit in what is left of a line are kept whole.
+void layout_clustered(const KdTreeHost& T, DeviceTree& out);
+
+// Walks the host tree and the device tree side by side: same splits, axes and child order, and at
+// every leaf the same primitives in the same order.  Returns false and a message at the first
+// difference (used by the CPU tests through gigl_debug_check_layout).
+bool layout_verify(const KdTreeHost& T, const DeviceTree& D, const char** what);
+
+}  // namespace gigl

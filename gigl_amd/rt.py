@@ -26,7 +26,7 @@ SYMBOLS = [
     "gigl_fog_destroy", "gigl_transmittance_device", "gigl_sample_density", "gigl_debug_rescaled_eps",
     "gigl_set_option", "gigl_debug_last_stats", "gigl_compute_pi_density_device", "gigl_shade_surface_device",
     "gigl_tonemap_device", "gigl_volume_samples_device", "gigl_shadow_points_device", "gigl_shade_volume_device",
-    "gigl_depth_buffer_device", "gigl_combine_device",
+    "gigl_depth_buffer_device", "gigl_combine_device", "gigl_debug_check_layout",
 ]
 
 
@@ -91,6 +91,7 @@ def lib():
         L.gigl_debug_rescaled_eps.argtypes = [i, vp, u64, vp]
         L.gigl_set_option.argtypes = [C.c_char_p, i]
         L.gigl_debug_last_stats.argtypes = [vp]
+        L.gigl_debug_check_layout.argtypes = [vp, i, i, vp]
         L.gigl_compute_pi_density_device.argtypes = [vp, vp, vp, i, i, vp, vp]
         L.gigl_shade_surface_device.argtypes = [vp, vp, vp, vp, vp, vp, u64, vp, u32, vp, vp, vp, vp, vp, vp, vp, vp]
         L.gigl_tonemap_device.argtypes = [i, vp, u64, i, i, vp, vp]
@@ -220,6 +221,12 @@ class Scene:
         st = TreeStats()
         _check(lib().gigl_scene_stats(self.h, C.byref(st)))
         return st
+
+    def check_layout(self, layout=1, treelet_levels=3):
+        """Rebuilds the device layout on the host and checks it against the tree; returns its bytes."""
+        n = C.c_uint64(0)
+        _check(lib().gigl_debug_check_layout(self.h, layout, treelet_levels, C.byref(n)))
+        return n.value
 
     def export_tree(self):
         st = self.stats()

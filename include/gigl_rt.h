@@ -232,6 +232,13 @@ int gigl_sample_density(const gigl_fog* f, const float* pos, uint64_t n, float* 
  * exists so the parity tests can pin the device arithmetic of the traversal epsilon. */
 int gigl_debug_rescaled_eps(int device, const float* t, uint64_t n, float* out);
 
+/* Rebuilds the device layout of the scene's tree on the host (layout 0: level treelets of
+ * `treelet_levels` levels, 1: clustered lines; DESIGN.md "Data layout") and checks it node by node
+ * against the tree in the reference's encoding (same splits, axes, child order, leaf contents and
+ * order).  Works on host-only scenes; *bytes_out (optional) = device bytes of nodes + id lists.
+ * No counterpart in the reference: it pins that re-addressing changed addresses only. */
+int gigl_debug_check_layout(const gigl_scene* s, int layout, int treelet_levels, uint64_t* bytes_out);
+
 /* Scheduling counters of the last closest-hit launch made with option "stats" = 1 (instrumented
  * kernel build; diagnostic only): rounds, T-phase iterations, T lane-steps, L-phase rounds,
  * L lane-rounds, refills, refilled lanes, sum over rounds of lanes holding a ray; then, on the

@@ -70,6 +70,22 @@ def test_builder_is_independent_of_thread_count(cornell):
     a.close()
 
 
+def test_device_layouts_keep_the_tree(cornell):
+    # re-addressing for the device (level treelets, clustered lines with inline id lists) changes
+    # addresses only: every split, axis, child order and leaf list is checked against the host tree
+    scenes = [(cornell["verts"], cornell["tris"])]
+    scenes += [synth.tessellate(cornell["verts"], cornell["tris"], k) for k in (3, 12, 40)]
+    V1 = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 0]], np.float32)
+    scenes += [(V1, np.array(t, np.uint32)) for t in ([[0, 1, 2, 0]], [[0, 1, 2, 0]] * 40, [[0, 1, 2, 0]] * 3)]
+    scenes.append((np.zeros((0, 3), np.float32), np.zeros((0, 4), np.uint32)))
+    for V, T in scenes:
+        for params in (S.KD_PARAMS, dict(inters_cost=10, trav_cost=1, max_depth=4, min_num_prims=2, empty_bonus=0.25)):
+            ps = rt.Scene(V, T, device=-1, **params)
+            sizes = [ps.check_layout(0, lv) for lv in (1, 2, 3, 4, 5)] + [ps.check_layout(1)]
+            assert all(b >= 16 for b in sizes)
+            ps.close()
+
+
 def test_empty_and_degenerate_scenes():
     e = rt.Scene(np.zeros((0, 3), np.float32), np.zeros((0, 4), np.uint32), device=-1)
     assert e.stats().n_nodes == 0

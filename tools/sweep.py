@@ -4,7 +4,7 @@
 usage: python3 tools/sweep.py [--tess 158] [--rays-log2 24] [--rounds 3] name=v,name=v ...
 Each positional argument is one variant: a comma-separated list of gigl_set_option pairs, plus the
 pseudo-options `sorted=1` (rays pre-sorted on the host by origin cell + direction octant) and
-`any=1` (any-hit instead of closest-hit).
+`any=1` (any-hit instead of closest-hit) and `layout=L` (scene created under device layout L).
 """
 import argparse
 import os
@@ -46,8 +46,15 @@ def main():
     V, T = synth.tessellate(cv, ct, a.tess) if a.tess > 1 else (cv, ct)
     if a.treelet:
         rt.set_option("treelet_levels", a.treelet)
-    scene = rt.Scene(V, T, device=0, **S.KD_PARAMS)
-    print("device bytes", scene.stats().device_bytes, flush=True)
+    scenes = {}
+
+    def scene_for(layout):   # layout=L: a scene created under that device layout (kd_layout.h)
+        if layout not in scenes:
+            rt.set_option("layout", layout)
+            scenes[layout] = rt.Scene(V, T, device=0, **S.KD_PARAMS)
+            print("layout", layout, "device bytes", scenes[layout].stats().device_bytes, flush=True)
+        return scenes[layout]
+    scene = scene_for(1)
     n = 1 << a.rays_log2
     ro, rd = synth.bounce_rays(V, T, n, synth.RAY_SEED_16M)
     d_o, d_d = torch.from_numpy(ro).to(dev), torch.from_numpy(rd).to(dev)
@@ -68,7 +75,7 @@ def main():
     for r in range(a.rounds + 1):
         for v in a.variants:
             opts = dict(defaults)
-            pseudo = {"sorted": 0, "any": 0, "stats": 0}
+            pseudo = {"sorted": 0, "any": 0, "stats": 0, "layout": 1}
             for kv in v.split(","):
                 if not kv or kv == "base":
                     continue
@@ -78,6 +85,7 @@ def main():
                 rt.set_option(k, val)
             rt.set_option("stats", pseudo["stats"])
             o, d = presorted(pseudo["sorted"]) if pseudo["sorted"] else (d_o, d_d)
+            scene = scene_for(pseudo["layout"])
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             # the first of the two launches is untimed: a variant with a different grid makes the
             # stream-ordered pool allocate a new workspace block, which costs ~0.5 ms once
@@ -108,7 +116,8 @@ def main():
         t = np.array(res[v])
         print("%-60s median %8.3f ms  min %8.3f ms  -> %8.1f Mrays/s" % (v, np.median(t), t.min(), n / np.median(t) / 1e3),
               flush=True)
-    scene.close()
+    for sc in scenes.values():
+        sc.close()
 
 
 if __name__ == "__main__":
