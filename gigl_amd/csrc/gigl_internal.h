@@ -18,8 +18,9 @@
 #ifndef GIGL_STREAM_HINT
 #define GIGL_STREAM_HINT 1
 #endif
-#ifndef GIGL_EARLY_PAIR
-#define GIGL_EARLY_PAIR 1
+
+#ifndef GIGL_COND_T1
+#define GIGL_COND_T1 1
 #endif
 
 #include <cfloat>
@@ -104,12 +105,13 @@ __device__ __forceinline__ bool box_intersect(const BoxF& b, const RayReg& r, fl
 
 struct TraceParams {
     const uint2* nodes;
+    uint2 root;           // the root node's two words (slot 0 of nodes)
     const unsigned* leaf_ids;
     const float4* tris;   // kTriStride float4 per triangle: (p0.xyz,e0.x) (e0.yz,e1.xy) (e1.z,mat,-,-) (-)
     BoxF box;
     unsigned n;
     unsigned* counter;
-    uint2* spill;
+    uint4* spill;         // (t_split, w0, w1, -) entries beyond the LDS stack
     unsigned spill_stride;
     int refill_thresh;
     int any_atomic;
@@ -268,6 +270,7 @@ struct gigl_scene {
     gigl::KdTreeHost tree;
     uint32_t n_tris = 0;
     uint2* d_nodes = nullptr;
+    uint2 root = {0u, 0x80000000u};
     unsigned* d_leaf_ids = nullptr;
     float4* d_tris = nullptr;
     gd::BoxF box;

@@ -172,13 +172,15 @@ __device__ __forceinline__ bool tri_test(const TriRec& T, unsigned id, const Ray
 
 // Spill-area accesses are opaque to the optimizer on purpose: merged with the LDS path they
 // turn every stack access into a flat_* instruction.
-__device__ __forceinline__ void spill_store(uint2* p, uint2 e) {
-    asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(e) : "memory");
+typedef unsigned spill_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void spill_store(uint4* p, unsigned a, unsigned b, unsigned c) {
+    spill_t e; e.x = a; e.y = b; e.z = c; e.w = 0u;
+    asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(e) : "memory");
 }
-__device__ __forceinline__ uint2 spill_load(const uint2* p) {
-    uint2 e;
-    asm volatile("global_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(e) : "v"(p) : "memory");
-    return e;
+__device__ __forceinline__ void spill_load(const uint4* p, unsigned& a, unsigned& b, unsigned& c) {
+    spill_t e;
+    asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(e) : "v"(p) : "memory");
+    a = e.x; b = e.y; c = e.z;
 }
 
 // Device node encoding (same topology and numbering as the reference's m_nodes, KdTree.h:22-65):
@@ -192,7 +194,10 @@ __device__ __forceinline__ uint2 spill_load(const uint2* p) {
 // A lane without a ray always holds a leaf word, so the T-phase test needs no have_ray term.
 template <bool ANY, int GEN, int STACK_N, int BLOCK, bool STATS = false>
 __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
-    __shared__ uint2 s_stack[STACK_N * BLOCK];
+    // stack entry = (t_split, the far child's two node words): the child pair is in registers when
+    // the entry is pushed, so a pop costs no global load
+    __shared__ uint2 s_stack[STACK_N * BLOCK];     // (t_split, w1)
+    __shared__ unsigned s_stack0[STACK_N * BLOCK]; // w0
     __shared__ float s_eps[kEpsTable];
     const unsigned tid = threadIdx.x;
     const unsigned lane = tid & 63u;
@@ -200,13 +205,14 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
     __syncthreads();
     auto eps_of = [&](float t) { return s_eps[(unsigned)(__builtin_amdgcn_frexp_expf(t) + kEpsBias)]; };
     uint2* const my_stack = s_stack + tid;
-    uint2* const my_spill = P.spill + ((size_t)blockIdx.x * BLOCK + tid);
+    unsigned* const my_stack0 = s_stack0 + tid;
+    uint4* const my_spill = P.spill + ((size_t)blockIdx.x * BLOCK + tid);
 
     RayReg r;
     float root_tmax = 0.0f;
     float best_t = FLT_MAX, best_u = 0.0f, best_v = 0.0f;
     unsigned best_id = kMiss;
-    unsigned node = 0, ray_idx = 0;
+    unsigned ray_idx = 0;
     int sp = -1;
     bool have_ray = false, pool_empty = false;
     // wave-local slice of the ray index space, refilled CHUNK rays at a time with one atomic
@@ -216,15 +222,30 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
     bool occ = false;
     const bool group_mode = ANY && !P.any_atomic;
 
-    auto push = [&](float t_split, unsigned id) {
+    auto push = [&](float t_split, unsigned w0, unsigned w1) {
         ++sp;
-        const uint2 e = make_uint2(__float_as_uint(t_split), id);
-        if (STACK_N >= 32 || sp < STACK_N) my_stack[sp * BLOCK] = e;
-        else spill_store(my_spill + (size_t)(sp - STACK_N) * P.spill_stride, e);
+        if (STACK_N >= 32 || sp < STACK_N) {
+            my_stack[sp * BLOCK] = make_uint2(__float_as_uint(t_split), w1);
+            my_stack0[sp * BLOCK] = w0;
+        } else spill_store(my_spill + (size_t)(sp - STACK_N) * P.spill_stride, __float_as_uint(t_split), w0, w1);
     };
-    auto peek = [&](int k) -> uint2 {
-        if (STACK_N >= 32 || k < STACK_N) return my_stack[k * BLOCK];
-        return spill_load(my_spill + (size_t)(k - STACK_N) * P.spill_stride);
+    auto peek_t = [&](int k) -> float {   // t_split of entry k
+        if (STACK_N >= 32 || k < STACK_N) return __uint_as_float(my_stack[k * BLOCK].x);
+        unsigned a, b, c;
+        spill_load(my_spill + (size_t)(k - STACK_N) * P.spill_stride, a, b, c);
+        return __uint_as_float(a);
+    };
+    auto peek = [&](int k, float& t_split, uint2& words) {
+        if (STACK_N >= 32 || k < STACK_N) {
+            const uint2 e = my_stack[k * BLOCK];
+            t_split = __uint_as_float(e.x);
+            words = make_uint2(my_stack0[k * BLOCK], e.y);
+        } else {
+            unsigned a, b, c;
+            spill_load(my_spill + (size_t)(k - STACK_N) * P.spill_stride, a, b, c);
+            t_split = __uint_as_float(a);
+            words = make_uint2(b, c);
+        }
     };
     auto finish = [&](bool hit) {
         if (ANY) {
@@ -246,7 +267,6 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
     // triangle tests per lane at a leaf).  Per ray the sequence of operations is the reference's.
     uint2 nd = make_uint2(0u, kLeafBit);
     unsigned leaf_i = 0;
-    bool need_load = false;
     const int t_exit = P.t_exit;
     // STATS build only: wave-level round counts and lane-level work counts (tools/sweep.py stats=1)
     const unsigned long long st_t0 = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;
@@ -309,7 +329,7 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
                                 go = !(best_t < r.tmin);  // KdTree.hpp:280
                             }
                         }
-                        if (go) { have_ray = true; node = 0; sp = -1; need_load = true; leaf_i = 0; }
+                        if (go) { have_ray = true; nd = P.root; sp = -1; leaf_i = 0; }
                         else finish(false);
                     }
                 }
@@ -320,10 +340,6 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
             if (pool_empty) break;
             continue;
         }
-        if (have_ray && need_load) {
-            nd = P.nodes[node];
-            need_load = false;
-        }
         // ---- T-phase: KdTree.hpp:284-311 ----
         for (;;) {
             const bool is_t = (int)nd.y >= 0;
@@ -333,11 +349,9 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
             if (is_t) {
                 const unsigned axis = nd.y & 3u;
                 const unsigned pair = nd.y >> 2;   // slot of the bottom child; the top child is the next slot
-#if GIGL_EARLY_PAIR
                 // both children (one aligned 16-byte pair) are requested before the step is decided,
                 // so the decision's arithmetic overlaps the memory round trip
                 const uint4 kids = *reinterpret_cast<const uint4*>(P.nodes + pair);
-#endif
                 const float split = __uint_as_float(nd.x);
                 const float oa = sel3(axis, r.ox, r.oy, r.oz);
                 const float ia = sel3(axis, r.ix, r.iy, r.iz);
@@ -355,15 +369,10 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
                 const bool take_second = !only_first & only_second;
                 // first = bottom_first ? pair : pair + 1, second = the other slot
                 if (!(only_first | only_second)) {  // both children: the far one waits on the stack
-                    push(t_split, pair + (bottom_first ? 1u : 0u));
+                    push(t_split, bottom_first ? kids.z : kids.x, bottom_first ? kids.w : kids.y);
                     r.tmax = t_split + eps_of(t_split);
                 }
-#if GIGL_EARLY_PAIR
                 nd = (bottom_first == take_second) ? make_uint2(kids.z, kids.w) : make_uint2(kids.x, kids.y);
-#else
-                node = pair + (bottom_first == take_second ? 1u : 0u);
-                nd = P.nodes[node];
-#endif
             }
             if ((int)__popcll(m_t) < t_exit) break;
         }
@@ -381,14 +390,20 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
                 unsigned id0, id1;
                 const bool two = leaf_i + 1 < n_prims;
                 if (kind == 3u) {
-                    id0 = P.leaf_ids[nd.x + leaf_i];
-                    id1 = two ? P.leaf_ids[nd.x + leaf_i + 1] : id0;
+                    // lists are 8-byte aligned and padded to an even length (kd_layout.h)
+                    const uint2 two_ids = *reinterpret_cast<const uint2*>(P.leaf_ids + nd.x + leaf_i);
+                    id0 = two_ids.x; id1 = two_ids.y;
                 } else {
                     id0 = nd.x;
-                    id1 = two ? (nd.y & kLeafPayload) : id0;
+                    id1 = nd.y & kLeafPayload;
                 }
                 const TriRec t0 = load_tri(P.tris, id0);
-                const TriRec t1 = load_tri(P.tris, id1);
+#if GIGL_COND_T1
+                TriRec t1 = t0;
+                if (two) t1 = load_tri(P.tris, id1);   // a lane's loads are what the memory pipeline counts
+#else
+                const TriRec t1 = load_tri(P.tris, two ? id1 : id0);
+#endif
                 bool hit = tri_test(t0, id0, r, best_t, best_u, best_v, best_id);
                 if (!(ANY && hit) && two) hit = tri_test(t1, id1, r, best_t, best_u, best_v, best_id) || hit;
                 any_done = ANY && hit;
@@ -404,19 +419,19 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
                     // t_split - eps(t_split) (:305) and the stored t_max is always the t_max set when
                     // the entry below was pushed, t_split' + eps(t_split') (:310), or the root t_max
                     // for the bottom entry, so both are rebuilt from the stored t_split values.
-                    const uint2 e = peek(sp);
-                    const float ts = __uint_as_float(e.x);
-                    node = e.y;
+                    float ts;
+                    uint2 far_words;
+                    peek(sp, ts, far_words);
                     r.tmin = ts - eps_of(ts);
                     if (sp > 0) {
-                        const float tb = __uint_as_float(peek(sp - 1).x);
+                        const float tb = peek_t(sp - 1);
                         r.tmax = tb + eps_of(tb);
                     } else {
                         r.tmax = root_tmax;
                     }
                     --sp;
                     if (best_t < r.tmin) finish(false);  // KdTree.hpp:280
-                    else { need_load = true; leaf_i = 0; }
+                    else { nd = far_words; leaf_i = 0; }
                 } else {
                     finish(false);
                 }
@@ -619,7 +634,7 @@ int launch_trace_t(const gigl_scene* s, TraceParams& P, const Options& opt, hipS
     if (grid == 0) return GIGL_OK;
     const bool spill = STACK_N < 32 && s->tree.actual_depth - 1 > STACK_N;
     const size_t spill_entries = spill ? (size_t)grid * kBlock * (size_t)(32 - STACK_N) : 0;
-    const size_t ws_bytes = 256 + spill_entries * sizeof(uint2);
+    const size_t ws_bytes = 256 + spill_entries * sizeof(uint4);
     void* ws = nullptr;
     HIP_TRY(hipMallocAsync(&ws, ws_bytes, st));
     if (hipMemsetAsync(ws, 0, 256, st) != hipSuccess) {
@@ -627,7 +642,7 @@ int launch_trace_t(const gigl_scene* s, TraceParams& P, const Options& opt, hipS
         return fail(GIGL_ERR_HIP, "hipMemsetAsync(workspace)");
     }
     P.counter = (unsigned*)ws;
-    P.spill = (uint2*)((char*)ws + 256);
+    P.spill = (uint4*)((char*)ws + 256);
     P.spill_stride = grid * kBlock;
     // guided requests only for batches that are long against the machine: a small batch would run
     // on minimum-size requests from its first ray (one atomic round trip per refill)
@@ -658,6 +673,7 @@ int launch_trace(const gigl_scene* s, TraceParams& P, hipStream_t st) {
         opt = g_opt;
     }
     P.nodes = s->d_nodes;
+    P.root = s->root;
     P.leaf_ids = s->d_leaf_ids ? s->d_leaf_ids : reinterpret_cast<const unsigned*>(s->d_nodes);  // clustered: lists in the node buffer
     P.tris = s->d_tris;
     P.box = s->box;
@@ -757,7 +773,7 @@ int gigl_debug_check_layout(const gigl_scene* s, int layout, int treelet_levels,
     else gigl::layout_levels(s->tree, treelet_levels, dt);
     const char* what = nullptr;
     if (!gigl::layout_verify(s->tree, dt, &what)) return fail(GIGL_ERR_BUILD, std::string("device layout differs from the host tree: ") + (what ? what : "?"));
-    if (bytes_out) *bytes_out = dt.slots.size() * 8 + (dt.ids_inline ? 0 : s->tree.leaf_prim_ids.size() * 4);
+    if (bytes_out) *bytes_out = dt.slots.size() * 8 + (dt.ids_inline ? 0 : dt.ids.size() * 4);
     return GIGL_OK;
 }
 
@@ -901,7 +917,7 @@ int gigl_scene_create(const float* verts, uint32_t n_verts, const uint32_t* tris
         return fail(GIGL_ERR_TOO_LARGE, "scene exceeds the device node encoding (2^29 triangles / node slots)");
     }
     const size_t nb_nodes = std::max<size_t>(dn.size(), 2) * sizeof(uint2);
-    const size_t nb_leaf = ids_inline ? 0 : std::max<size_t>(s->tree.leaf_prim_ids.size(), 1) * 4;
+    const size_t nb_leaf = ids_inline ? 0 : std::max<size_t>(dtree.ids.size() + 2, 2) * 4;
     const size_t nb_tris = std::max<size_t>(rec.size(), 16) * 4;
     auto cleanup = [&]() {
         if (s->d_nodes) (void)hipFree(s->d_nodes);
@@ -923,9 +939,9 @@ int gigl_scene_create(const float* verts, uint32_t n_verts, const uint32_t* tris
     CREATE_TRY(hipMalloc((void**)&s->d_tris, nb_tris));
     CREATE_TRY(hipMalloc((void**)&s->d_one, 64));
     CREATE_TRY(hipMemcpy(s->d_nodes, dn.data(), dn.size() * 8, hipMemcpyHostToDevice));
-    if (!ids_inline && !s->tree.leaf_prim_ids.empty())
-        CREATE_TRY(hipMemcpy(s->d_leaf_ids, s->tree.leaf_prim_ids.data(), s->tree.leaf_prim_ids.size() * 4,
-                             hipMemcpyHostToDevice));
+    if (!ids_inline && !dtree.ids.empty())
+        CREATE_TRY(hipMemcpy(s->d_leaf_ids, dtree.ids.data(), dtree.ids.size() * 4, hipMemcpyHostToDevice));
+    s->root = make_uint2(dn[0].w0, dn[0].w1);
     if (!rec.empty()) CREATE_TRY(hipMemcpy(s->d_tris, rec.data(), rec.size() * 4, hipMemcpyHostToDevice));
 #undef CREATE_TRY
     s->box = BoxF{s->tree.box_min[0], s->tree.box_min[1], s->tree.box_min[2],

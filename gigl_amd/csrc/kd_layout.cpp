@@ -37,7 +37,18 @@ inline KdNode device_leaf(const KdTreeHost& T, const KdNode& h) {
 void layout_levels(const KdTreeHost& T, int levels, DeviceTree& dt) {
     std::vector<KdNode>& out = dt.slots;
     dt.ids_inline = false;
+    dt.ids.clear();
     out.clear();
+    auto dev_leaf = [&](const KdNode& h) {
+        KdNode nd = device_leaf(T, h);
+        const uint32_t n = h.w1 >> 1;
+        if (n >= 3u) {   // copy the list to an even offset, padded to an even length
+            nd.w0 = (uint32_t)dt.ids.size();
+            for (uint32_t i = 0; i < n; ++i) dt.ids.push_back(T.leaf_prim_ids[h.w0 + i]);
+            if (n & 1u) dt.ids.push_back(0u);
+        }
+        return nd;
+    };
     const std::vector<KdNode>& H = T.nodes;
     if (dt.slot_of_host) dt.slot_of_host->assign(H.size(), 0u);
     if (H.empty()) {  // empty scene: a single empty leaf (KdTree.hpp:9-12)
@@ -51,7 +62,7 @@ void layout_levels(const KdTreeHost& T, int levels, DeviceTree& dt) {
     const unsigned line_pairs = 8;                            // 128 B / 16 B
     struct Item { uint32_t host; uint32_t slot; };            // interior host node, its device slot
     std::vector<Item> roots, cur, nxt;
-    if (is_leaf(H[0])) { out[0] = device_leaf(T, H[0]); return; }
+    if (is_leaf(H[0])) { out[0] = dev_leaf(H[0]); return; }
     out[0] = KdNode{H[0].w0, (H[0].w1 >> 1) & 3u};
     roots.push_back(Item{0u, 0u});
     while (!roots.empty()) {
@@ -86,7 +97,7 @@ void layout_levels(const KdTreeHost& T, int levels, DeviceTree& dt) {
                 for (uint32_t k : kids) {
                     const uint32_t slot = (uint32_t)out.size();
                     if (dt.slot_of_host) (*dt.slot_of_host)[k] = slot;
-                    if (is_leaf(H[k])) out.push_back(device_leaf(T, H[k]));
+                    if (is_leaf(H[k])) out.push_back(dev_leaf(H[k]));
                     else {
                         out.push_back(KdNode{H[k].w0, (H[k].w1 >> 1) & 3u});
                         (lv + 1 < levels ? nxt : frontier).push_back(Item{k, slot});
@@ -134,7 +145,7 @@ void layout_clustered(const KdTreeHost& T, DeviceTree& dt) {
     auto list_dw = [&](uint32_t k) -> uint32_t {
         if (!is_leaf(H[k])) return 0u;
         const uint32_t n = H[k].w1 >> 1;
-        return n >= 3u ? n : 0u;
+        return n >= 3u ? ((n + 1u) & ~1u) : 0u;               // padded to an even length (8-byte loads)
     };
     auto pair_cost = [&](uint32_t host, uint32_t& l0, uint32_t& l1) -> uint32_t {
         l0 = list_dw(host + 1u);
@@ -216,7 +227,9 @@ void layout_clustered(const KdTreeHost& T, DeviceTree& dt) {
                     else if (lists[j]) {
                         back -= lists[j];
                         nd.w0 = line + back;
-                        for (uint32_t i = 0; i < lists[j]; ++i) W[line + back + i] = T.leaf_prim_ids[H[k].w0 + i];
+                        const uint32_t n = H[k].w1 >> 1;
+                        for (uint32_t i = 0; i < n; ++i) W[line + back + i] = T.leaf_prim_ids[H[k].w0 + i];
+                        if (n & 1u) W[line + back + n] = 0u;
                     }
                     put_node(kd, nd);
                 } else {
@@ -241,9 +254,11 @@ void layout_clustered(const KdTreeHost& T, DeviceTree& dt) {
     }
     for (const Overflow& o : overflow) {
         const uint32_t n = H[o.host].w1 >> 1;
+        if (W.size() & 1u) W.push_back(0u);
         W[o.at_dw] = (uint32_t)W.size();
         for (uint32_t i = 0; i < n; ++i) W.push_back(T.leaf_prim_ids[H[o.host].w0 + i]);
     }
+    W.push_back(0u);   // the last list may be read one id past its end
     if (W.size() & 1u) W.push_back(0u);
     dt.slots.resize(W.size() / 2);
     std::memcpy(dt.slots.data(), W.data(), W.size() * 4);
@@ -255,8 +270,8 @@ bool layout_verify(const KdTreeHost& T, const DeviceTree& D, const char** what) 
     const std::vector<KdNode>& S = D.slots;
     if (S.size() < 2) return bad("device tree has no root pair");
     if (H.empty()) return S[0].w1 == kDevLeafBit ? true : bad("empty tree must be an empty leaf");
-    const uint32_t* ids = D.ids_inline ? reinterpret_cast<const uint32_t*>(S.data()) : T.leaf_prim_ids.data();
-    const size_t n_ids = D.ids_inline ? S.size() * 2 : T.leaf_prim_ids.size();
+    const uint32_t* ids = D.ids_inline ? reinterpret_cast<const uint32_t*>(S.data()) : D.ids.data();
+    const size_t n_ids = D.ids_inline ? S.size() * 2 : D.ids.size();
     struct It { uint32_t host, slot; };
     std::vector<It> st(1, It{0u, 0u});
     size_t seen = 0;
@@ -275,7 +290,8 @@ bool layout_verify(const KdTreeHost& T, const DeviceTree& D, const char** what) 
             if (n == 2u && (d.w0 != T.leaf_prim_ids[h.w0] || pay != T.leaf_prim_ids[h.w0 + 1])) return bad("two-prim ids");
             if (n >= 3u) {
                 if (pay != n) return bad("leaf size");
-                if ((size_t)d.w0 + n > n_ids) return bad("id list out of range");
+                if (d.w0 & 1u) return bad("id list is not 8-byte aligned");
+                if ((size_t)d.w0 + ((n + 1u) & ~1u) > n_ids) return bad("id list out of range");
                 for (uint32_t i = 0; i < n; ++i)
                     if (ids[d.w0 + i] != T.leaf_prim_ids[h.w0 + i]) return bad("id list contents");
                 // a list inside the node buffer must not straddle into another line's nodes: it is

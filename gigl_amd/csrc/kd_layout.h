@@ -8,8 +8,10 @@
 //   leaf:     w1 bit 31 = 1, bits 29-30 = kind, bits 0-28 = payload
 //             kind 0 empty | 1 one prim (w0 = id) | 2 two prims (w0 = id0, payload = id1)
 //             kind 3: n >= 3 prims, payload = n, w0 = index of the id list in 4-byte units
-//                     (into leaf_prim_ids for the level layout, into the node buffer itself for
-//                     the clustered layout, which keeps the list in the leaf's own cache line)
+//                     (into DeviceTree::ids for the level layout, into the node buffer itself for
+//                     the clustered layout, which keeps the list in the leaf's own cache line).
+//                     Lists start on an 8-byte boundary and are padded to an even length, so
+//                     the kernel reads two ids with one load.
 #pragma once
 #include <cstdint>
 #include <vector>
@@ -22,7 +24,8 @@ constexpr uint32_t kDevLeafBit = 0x80000000u, kDevLeafPayload = 0x1FFFFFFFu;
 
 struct DeviceTree {
     std::vector<KdNode> slots;          // 8-byte slots: nodes (and, clustered layout, inline id lists)
-    bool ids_inline = false;            // kind-3 leaves index `slots` (as uint32) instead of leaf_prim_ids
+    bool ids_inline = false;            // kind-3 leaves index `slots` (as uint32) instead of `ids`
+    std::vector<uint32_t> ids;          // level layout: the id lists, each padded to an even length
     // optional diagnostics (filled when non-null on entry): device slot of every host node
     std::vector<uint32_t>* slot_of_host = nullptr;
 };

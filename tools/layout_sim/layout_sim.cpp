@@ -46,6 +46,8 @@ static float eps_of(float t) {
     return ldexpf(FLT_EPSILON, e + 1);
 }
 
+static uint64_t g_push_depth[64];   // pushes by stack depth before the push
+
 struct Tracer {
     const gigl::KdTreeHost& T;
     const float* V;
@@ -103,6 +105,7 @@ struct Tracer {
                 if (ts > tmax || ts <= 0.0f) node = first;
                 else if (ts < tmin) node = second;
                 else {
+                    ++g_push_depth[sp];
                     stack[sp++] = St{ts - eps_of(ts), tmax, second};
                     node = first;
                     tmax = ts + eps_of(ts);
@@ -226,6 +229,17 @@ int main(int argc, char** argv) {
     }
     for (const Ev& e : ev) { nodes += e.kind == 0u; tests += e.kind == 2u; }
     printf("rays %u: nodes/ray %.2f, tests/ray %.2f, hot set %zu lines\n", nr, nodes / nr, tests / nr, hot);
+    {
+        uint64_t tot = 0, acc = 0;
+        for (int i = 0; i < 64; ++i) tot += g_push_depth[i];
+        printf("pushes/ray %.2f; share of pushes landing at stack index >= k:", (double)tot / nr);
+        for (int k = 0; k < 20; ++k) {
+            if (k >= 6 && k <= 16) printf(" k=%d %.2f%%", k, 100.0 * (double)(tot - acc) / (double)tot);
+            acc += g_push_depth[k];
+        }
+        printf("\n");
+        if (argc > 3) return 0;
+    }
 
     TriLayout tl64;   // 64-byte records in id order (round 1)
     std::vector<uint32_t> slot_of;

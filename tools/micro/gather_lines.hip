@@ -33,11 +33,11 @@ __global__ void __launch_bounds__(256) gather(const uint4* __restrict__ table, u
 }
 
 int main(int argc, char** argv) {
-    const size_t mb = argc > 1 ? atol(argv[1]) : 150;
+    const double mb = argc > 1 ? atof(argv[1]) : 150;   // table size in MB (fractions allowed: 0.015625 = 16 KB, L1-resident)
     const unsigned stride = argc > 2 ? atoi(argv[2]) : 64;       // bytes between slots
     const int blocks_per_cu = argc > 3 ? atoi(argv[3]) : 6;
     const int iters = argc > 4 ? atoi(argv[4]) : 256;
-    const size_t bytes = mb << 20;
+    const size_t bytes = (size_t)(mb * 1048576.0);
     uint4* table; unsigned* out;
     hipMalloc((void**)&table, bytes);
     hipMemset(table, 1, bytes);
@@ -60,7 +60,7 @@ int main(int argc, char** argv) {
             if (rep > 0 && ms < best) best = ms;
         }
         const double lines = (double)grid * 256 * iters * 8;
-        printf("table %zu MB stride %u B, %d blocks/CU, %d loads in flight per lane: %.3f ms, %.1f G lines/s, %.2f TB/s at 64 B/line\n",
+        printf("table %g MB stride %u B, %d blocks/CU, %d loads in flight per lane: %.3f ms, %.1f G lines/s, %.2f TB/s at 64 B/line\n",
                mb, stride, blocks_per_cu, mlp, best, lines / best / 1e6, lines * 64 / best / 1e9);
     }
     if (stride == 128) {
@@ -73,7 +73,7 @@ int main(int argc, char** argv) {
             if (rep > 0 && ms < best) best = ms;
         }
         const double lines = (double)grid * 256 * iters * 8;
-        printf("table %zu MB, both 64-byte halves of random 128-byte lines: %.3f ms, %.1f G 128-byte lines/s, %.2f TB/s at 128 B/line\n",
+        printf("table %g MB, both 64-byte halves of random 128-byte lines: %.3f ms, %.1f G 128-byte lines/s, %.2f TB/s at 128 B/line\n",
                mb, best, lines / best / 1e6, lines * 128 / best / 1e9);
     }
     if (hipDeviceSynchronize() != hipSuccess) { printf("error\n"); return 1; }
