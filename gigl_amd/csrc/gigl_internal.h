@@ -106,6 +106,8 @@ __device__ __forceinline__ bool box_intersect(const BoxF& b, const RayReg& r, fl
 struct TraceParams {
     const uint2* nodes;
     uint2 root;           // the root node's two words (slot 0 of nodes)
+    const uint4* recs;    // triple layout: the same buffer as 16-byte records
+    uint4 root_rec;       // triple layout: record 0
     const unsigned* leaf_ids;
     const float4* tris;   // kTriStride float4 per triangle: (p0.xyz,e0.x) (e0.yz,e1.xy) (e1.z,mat,-,-) (-)
     BoxF box;
@@ -271,6 +273,8 @@ struct gigl_scene {
     uint32_t n_tris = 0;
     uint2* d_nodes = nullptr;
     uint2 root = {0u, 0x80000000u};
+    uint4 root_rec = {0u, 0u, 0u, 3u};
+    bool triples = false;          // d_nodes holds the triple layout (trace3_kernel)
     unsigned* d_leaf_ids = nullptr;
     float4* d_tris = nullptr;
     gd::BoxF box;

@@ -461,6 +461,263 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
     }
 }
 
+// ---- traversal over the triple layout (kd_layout.h: layout_triples) ------------------------------
+// One 16-byte record holds a node at an even depth and both of its children, so one load serves two
+// levels of the descent: half the per-lane loads and half the dependent round trips of trace_kernel.
+// Per ray the sequence of reference operations (KdTree.hpp:266-347) is unchanged; scheduling (wave
+// pool, refill, T/L phases, stack) is trace_kernel's.  Lane state: lvl 0 = `rec` is the record of the
+// current node (interior record, or leaf record when (rec.w & 3) == 3); lvl 1 = the current node is
+// a child inside a record: rec.x = its slot (split or leaf payload), rec.y = type | block unit << 3.
+// Stack entries are (t_split, w0, w1): w1 bit 2 clear = a lvl-1 node (w0 = slot, w1 = rec.y), set = a
+// record still to be loaded (unit = w1 >> 3).
+template <bool ANY, int GEN, int STACK_N, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) trace3_kernel(const TraceParams P) {
+    __shared__ uint2 s_stack[STACK_N * BLOCK];     // (t_split, w1)
+    __shared__ unsigned s_stack0[STACK_N * BLOCK]; // w0
+    __shared__ float s_eps[kEpsTable];
+    const unsigned tid = threadIdx.x;
+    const unsigned lane = tid & 63u;
+    for (int i = (int)tid; i < kEpsTable; i += BLOCK) s_eps[i] = eps_from_exp(i - kEpsBias + 1);
+    __syncthreads();
+    auto eps_of = [&](float t) { return s_eps[(unsigned)(__builtin_amdgcn_frexp_expf(t) + kEpsBias)]; };
+    uint2* const my_stack = s_stack + tid;
+    unsigned* const my_stack0 = s_stack0 + tid;
+    uint4* const my_spill = P.spill + ((size_t)blockIdx.x * BLOCK + tid);
+    const uint4* __restrict__ recs = P.recs;
+
+    RayReg r;
+    float root_tmax = 0.0f;
+    float best_t = FLT_MAX, best_u = 0.0f, best_v = 0.0f;
+    unsigned best_id = kMiss;
+    unsigned ray_idx = 0;
+    int sp = -1;
+    bool have_ray = false, pool_empty = false;
+    unsigned pool_next = 0, pool_end = 0, last_base = 0;
+    unsigned group_base = kMiss;
+    bool occ = false;
+    const bool group_mode = ANY && !P.any_atomic;
+
+    auto push = [&](float t_split, unsigned w0, unsigned w1) {
+        ++sp;
+        if (STACK_N >= 32 || sp < STACK_N) {
+            my_stack[sp * BLOCK] = make_uint2(__float_as_uint(t_split), w1);
+            my_stack0[sp * BLOCK] = w0;
+        } else spill_store(my_spill + (size_t)(sp - STACK_N) * P.spill_stride, __float_as_uint(t_split), w0, w1);
+    };
+    auto peek_t = [&](int k) -> float {
+        if (STACK_N >= 32 || k < STACK_N) return __uint_as_float(my_stack[k * BLOCK].x);
+        unsigned a, b, c;
+        spill_load(my_spill + (size_t)(k - STACK_N) * P.spill_stride, a, b, c);
+        return __uint_as_float(a);
+    };
+    auto peek = [&](int k, float& t_split, unsigned& w0, unsigned& w1) {
+        if (STACK_N >= 32 || k < STACK_N) {
+            const uint2 e = my_stack[k * BLOCK];
+            t_split = __uint_as_float(e.x);
+            w0 = my_stack0[k * BLOCK];
+            w1 = e.y;
+        } else {
+            unsigned a;
+            spill_load(my_spill + (size_t)(k - STACK_N) * P.spill_stride, a, w0, w1);
+            t_split = __uint_as_float(a);
+        }
+    };
+    auto finish = [&](bool hit) {
+        if (ANY) {
+            if (group_mode) occ = hit;
+            else if (hit) atomicOr(((unsigned*)P.bits) + (ray_idx >> 5), 1u << (ray_idx & 31u));
+        } else {
+            stream_store(P.hits + ray_idx, hit ? make_uint4(best_id, __float_as_uint(best_t), __float_as_uint(best_u),
+                                                            __float_as_uint(best_v))
+                                               : make_uint4(kMiss, __float_as_uint(FLT_MAX), 0u, 0u));
+            if (P.ranges) P.ranges[ray_idx] = make_float2(r.tmin, r.tmax);
+        }
+        have_ray = false;
+    };
+
+    uint4 rec = make_uint4(0u, 0u, 0u, 3u);   // a lane without a ray holds an empty leaf record
+    unsigned lvl = 0, leaf_i = 0;
+    const int t_exit = P.t_exit;
+
+    // one interior step, KdTree.hpp:288-311: which child first, which children at all
+    struct Step { float t_split; bool bottom_first, both, take_top; };
+    auto decide = [&](unsigned axis, float split) -> Step {
+        const float oa = sel3(axis, r.ox, r.oy, r.oz);
+        const float ia = sel3(axis, r.ix, r.iy, r.iz);
+        bool bottom_first = oa < split;
+        if (__ballot(oa == split) != 0ull) {
+            asm volatile("" ::: "memory");
+            bottom_first = bottom_first | ((oa == split) & (sel3(axis, r.dx, r.dy, r.dz) <= 0.0f));
+        }
+        Step s;
+        s.t_split = (split - oa) * ia;
+        const bool only_first = (s.t_split > r.tmax) | (s.t_split <= 0.0f);
+        const bool only_second = s.t_split < r.tmin;
+        s.bottom_first = bottom_first;
+        s.both = !(only_first | only_second);
+        s.take_top = bottom_first == (!only_first & only_second);   // the child entered now is the top one
+        return s;
+    };
+
+    for (;;) {
+        const unsigned long long idle = __ballot(!have_ray);
+        const int n_idle = __popcll(idle);
+        if (n_idle >= P.refill_thresh && !pool_empty) {
+            if (group_mode) {
+                const unsigned long long m = __ballot(occ);
+                if (group_base != kMiss && lane == 0) P.bits[group_base >> 6] = m;
+                occ = false;
+                group_base = kMiss;
+            }
+            if (pool_next == pool_end) {
+                unsigned base = 0, take_n = P.chunk;
+                if (P.guided) {
+                    const unsigned rem = last_base < P.n ? P.n - last_base : 0u;
+                    const unsigned g = (rem / P.guided) & ~63u;
+                    take_n = g < 64u ? 64u : (g < P.chunk ? g : P.chunk);
+                }
+                if (lane == 0) base = atomicAdd(P.counter, take_n);
+                base = __builtin_amdgcn_readfirstlane(base);
+                last_base = base;
+                pool_next = base < P.n ? base : P.n;
+                pool_end = (P.n - pool_next) < take_n ? P.n : pool_next + take_n;
+                if (pool_next == pool_end) pool_empty = true;
+            }
+            if (!pool_empty) {
+                const unsigned avail = pool_end - pool_next;
+                const unsigned take = (unsigned)n_idle < avail ? (unsigned)n_idle : avail;
+                if (group_mode) group_base = pool_next;
+                if (!have_ray) {
+                    const unsigned rank = __popcll(idle & ((1ull << lane) - 1ull));
+                    if (rank < take) {
+                        unsigned idx = pool_next + rank;
+                        if (GEN == 0 && P.perm) idx = P.perm[idx];
+                        ray_idx = idx;
+                        best_t = FLT_MAX; best_u = 0.0f; best_v = 0.0f; best_id = kMiss;
+                        bool go = fetch_ray<GEN>(P, idx, r);
+                        if (go) {
+                            float entr, exit;
+                            go = box_intersect(P.box, r, entr, exit);
+                            if (go) {
+                                const float nmin = gmax(r.tmin, entr - eps_of(entr));
+                                const float nmax = gmin(r.tmax, exit + eps_of(exit));
+                                r.tmin = nmin; r.tmax = nmax;
+                                root_tmax = nmax;
+                                go = !(best_t < r.tmin);
+                            }
+                        }
+                        if (go) { have_ray = true; rec = P.root_rec; lvl = 0; sp = -1; leaf_i = 0; }
+                        else finish(false);
+                    }
+                }
+                pool_next = __builtin_amdgcn_readfirstlane(pool_next + take);
+            }
+        }
+        if (__ballot(have_ray) == 0ull) {
+            if (pool_empty) break;
+            continue;
+        }
+        // ---- T-phase: up to two levels and exactly one record load per lane and iteration ----
+        for (;;) {
+            const bool is_t = ((lvl == 0u ? rec.w : rec.y) & 3u) != 3u;
+            const unsigned long long m_t = __ballot(is_t);
+            if (m_t == 0ull) break;
+            if (is_t) {
+                if (lvl == 0u) {   // a node with both children in its record: no load
+                    const Step s = decide(rec.w & 3u, __uint_as_float(rec.x));
+                    const unsigned type_a = (rec.w >> 2) & 3u, type_b = (rec.w >> 4) & 3u;
+                    const unsigned blk = (rec.w >> 6) << 1;                    // unit of A's children
+                    const unsigned blk_b = blk + (type_a != 3u ? 2u : 0u);     // unit of B's children
+                    const unsigned desc_a = type_a | (blk << 3), desc_b = type_b | (blk_b << 3);
+                    if (s.both) {      // the far child waits on the stack
+                        push(s.t_split, s.bottom_first ? rec.z : rec.y, s.bottom_first ? desc_b : desc_a);
+                        r.tmax = s.t_split + eps_of(s.t_split);
+                    }
+                    rec.x = s.take_top ? rec.z : rec.y;
+                    rec.y = s.take_top ? desc_b : desc_a;
+                    lvl = 1u;
+                }
+                if ((rec.y & 3u) != 3u) {   // a child inside a record: its children are records of their own
+                    const Step s = decide(rec.y & 3u, __uint_as_float(rec.x));
+                    const unsigned blk = rec.y >> 3;
+                    if (s.both) {
+                        push(s.t_split, 0u, 4u | ((blk + (s.bottom_first ? 1u : 0u)) << 3));
+                        r.tmax = s.t_split + eps_of(s.t_split);
+                    }
+                    rec = recs[blk + (s.take_top ? 1u : 0u)];
+                    lvl = 0u;
+                }
+            }
+            if ((int)__popcll(m_t) < t_exit) break;
+        }
+        // ---- L-phase: KdTree.hpp:312-343 ----
+        const bool at_leaf = have_ray && ((lvl == 0u ? rec.w : rec.y) & 3u) == 3u;
+        if (at_leaf) {
+            if (lvl == 1u) {   // a leaf inside a record: its payload names the prims
+                const unsigned payload = rec.x, kind = payload & 3u;
+                if (kind == 2u) rec = recs[payload >> 2];
+                else rec = make_uint4(payload >> 2, 0u, 0u, kind == 1u ? (3u | (1u << 2)) : 3u);
+                lvl = 0u;
+            }
+            const unsigned n_prims = rec.w >> 2;
+            bool any_done = false;
+            if (leaf_i < n_prims) {
+                unsigned id0, id1;
+                const bool two = leaf_i + 1 < n_prims;
+                if (n_prims <= 3u) {
+                    id0 = leaf_i == 0u ? rec.x : rec.z;
+                    id1 = rec.y;
+                } else {
+                    const uint2 two_ids = reinterpret_cast<const uint2*>(recs + rec.x)[leaf_i >> 1];
+                    id0 = two_ids.x; id1 = two_ids.y;
+                }
+                const TriRec t0 = load_tri(P.tris, id0);
+                const TriRec t1 = load_tri(P.tris, two ? id1 : id0);
+                bool hit = tri_test(t0, id0, r, best_t, best_u, best_v, best_id);
+                if (!(ANY && hit) && two) hit = tri_test(t1, id1, r, best_t, best_u, best_v, best_id) || hit;
+                any_done = ANY && hit;
+                leaf_i += 2;
+            }
+            if (any_done) {
+                finish(true);
+                rec.w = 3u; lvl = 0u;
+            } else if (leaf_i >= n_prims) {
+                if (best_id != kMiss) {
+                    finish(true);
+                    rec.w = 3u; lvl = 0u;
+                } else if (sp >= 0) {
+                    float ts;
+                    unsigned w0, w1;
+                    peek(sp, ts, w0, w1);
+                    r.tmin = ts - eps_of(ts);
+                    if (sp > 0) {
+                        const float tb = peek_t(sp - 1);
+                        r.tmax = tb + eps_of(tb);
+                    } else {
+                        r.tmax = root_tmax;
+                    }
+                    --sp;
+                    if (best_t < r.tmin) {   // KdTree.hpp:280
+                        finish(false);
+                        rec.w = 3u; lvl = 0u;
+                    } else {
+                        leaf_i = 0;
+                        if (w1 & 4u) { rec = recs[w1 >> 3]; lvl = 0u; }
+                        else { rec.x = w0; rec.y = w1; lvl = 1u; }
+                    }
+                } else {
+                    finish(false);
+                    rec.w = 3u; lvl = 0u;
+                }
+            }
+        }
+    }
+    if (group_mode) {
+        const unsigned long long m = __ballot(occ);
+        if (group_base != kMiss && lane == 0) P.bits[group_base >> 6] = m;
+    }
+}
+
 // ---- ray regrouping: coarse counting sort by (direction octant, Morton cell of the origin) -----
 // Incoherent batches are traced through a permutation that puts rays which start in the same cell
 // of the tree box and head into the same octant next to each other, so the lanes of a wave touch
@@ -591,7 +848,7 @@ int gd::fail(int code, const std::string& msg) {
 namespace {
 
 struct Options {
-    int stack_lds = 12;       // LDS entries per lane: 8, 12, 16 or 32
+    int stack_lds = 8;        // LDS entries per lane (12 bytes each): 8, 12, 16 or 32; 8 keeps 6 workgroups per CU
     int refill_thresh = 32;   // idle lanes that trigger a refill (closest-hit / atomic any-hit)
     int any_atomic = -1;      // 0: any-hit waves own 64 consecutive rays, one store per wave; 1: lane refill +
                               // atomicOr; -1: choose by tree depth (deep trees have long-tailed rays)
@@ -614,12 +871,12 @@ unsigned long long g_last_stats[12] = {0};
 
 template <bool ANY, int GEN, int STACK_N>
 int launch_trace_t(const gigl_scene* s, TraceParams& P, const Options& opt, hipStream_t st) {
-    auto kern = trace_kernel<ANY, GEN, STACK_N, kBlock>;
-    if (!ANY && GEN == 0 && STACK_N == 12 && opt.stats) kern = trace_kernel<ANY, GEN, 12, kBlock, true>;
+    auto kern = s->triples ? trace3_kernel<ANY, GEN, STACK_N, kBlock> : trace_kernel<ANY, GEN, STACK_N, kBlock>;
+    if (!s->triples && !ANY && GEN == 0 && STACK_N == 12 && opt.stats) kern = trace_kernel<ANY, GEN, 12, kBlock, true>;
     int per_cu = opt.blocks_per_cu;
     if (per_cu <= 0) {
-        static int cached[2] = {0, 0};  // per instantiation; [1] is the instrumented build
-        int& c = cached[(!ANY && GEN == 0 && STACK_N == 12 && opt.stats) ? 1 : 0];
+        static int cached[3] = {0, 0, 0};  // per instantiation; [1] is the instrumented build, [2] the triple-layout kernel
+        int& c = cached[s->triples ? 2 : (!ANY && GEN == 0 && STACK_N == 12 && opt.stats) ? 1 : 0];
         if (c <= 0) {
             int q = 0;
             HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, kern, kBlock, 0));
@@ -649,7 +906,7 @@ int launch_trace_t(const gigl_scene* s, TraceParams& P, const Options& opt, hipS
     P.guided = opt.guided > 0 ? grid * (kBlock / 64u) * (unsigned)opt.guided : 0u;
     if ((uint64_t)P.n < 2ull * P.guided * P.chunk) P.guided = 0u;
     P.stats = nullptr;
-    if (!ANY && GEN == 0 && STACK_N == 12 && opt.stats) {
+    if (!s->triples && !ANY && GEN == 0 && STACK_N == 12 && opt.stats) {
         P.stats = (unsigned long long*)((char*)ws + 128);
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, st, P);
@@ -674,6 +931,8 @@ int launch_trace(const gigl_scene* s, TraceParams& P, hipStream_t st) {
     }
     P.nodes = s->d_nodes;
     P.root = s->root;
+    P.recs = reinterpret_cast<const uint4*>(s->d_nodes);
+    P.root_rec = s->root_rec;
     P.leaf_ids = s->d_leaf_ids ? s->d_leaf_ids : reinterpret_cast<const unsigned*>(s->d_nodes);  // clustered: lists in the node buffer
     P.tris = s->d_tris;
     P.box = s->box;
@@ -767,9 +1026,11 @@ int gigl_device_count(int* count) {
 
 int gigl_debug_check_layout(const gigl_scene* s, int layout, int treelet_levels, uint64_t* bytes_out) {
     if (!s) return fail(GIGL_ERR_INVALID, "scene is NULL");
-    if (layout < 0 || layout > 1 || treelet_levels < 1 || treelet_levels > 5) return fail(GIGL_ERR_INVALID, "bad layout");
+    if (layout < 0 || layout > 2 || treelet_levels < 1 || treelet_levels > 5) return fail(GIGL_ERR_INVALID, "bad layout");
     gigl::DeviceTree dt;
-    if (layout == 1) gigl::layout_clustered(s->tree, dt);
+    if (layout == 2) {
+        if (!gigl::layout_triples(s->tree, dt)) return fail(GIGL_ERR_TOO_LARGE, "tree exceeds the triple-record encoding");
+    } else if (layout == 1) gigl::layout_clustered(s->tree, dt);
     else gigl::layout_levels(s->tree, treelet_levels, dt);
     const char* what = nullptr;
     if (!gigl::layout_verify(s->tree, dt, &what)) return fail(GIGL_ERR_BUILD, std::string("device layout differs from the host tree: ") + (what ? what : "?"));
@@ -805,7 +1066,7 @@ int gigl_set_option(const char* name, int value) {
         if (value < 1 || value > 5) return fail(GIGL_ERR_INVALID, "treelet_levels must be in 1..5");
         g_opt.treelet_levels = value;
     } else if (k == "layout") {
-        if (value < 0 || value > 1) return fail(GIGL_ERR_INVALID, "layout must be 0 or 1");
+        if (value < 0 || value > 2) return fail(GIGL_ERR_INVALID, "layout must be 0, 1 or 2");
         g_opt.layout = value;
     } else if (k == "sort_bits") {
         if (value < 4 || value > 6) return fail(GIGL_ERR_INVALID, "sort_bits must be in 4..6");
@@ -907,8 +1168,10 @@ int gigl_scene_create(const float* verts, uint32_t n_verts, const uint32_t* tris
     }
     // ---- device node array: same topology, cache-line treelet order (see flatten_nodes) ----
     gigl::DeviceTree dtree;
-    if (layout == 1) gigl::layout_clustered(s->tree, dtree);
-    else gigl::layout_levels(s->tree, treelet_levels, dtree);
+    if (layout == 2 && !gigl::layout_triples(s->tree, dtree)) layout = 1;   // beyond the record encoding: fall back
+    if (layout == 1) { dtree = gigl::DeviceTree(); gigl::layout_clustered(s->tree, dtree); }
+    else if (layout == 0) gigl::layout_levels(s->tree, treelet_levels, dtree);
+    s->triples = dtree.triples;
     const std::vector<gigl::KdNode>& dn = dtree.slots;
     const bool ids_inline = dtree.ids_inline;
     // device node word 1 keeps 29 bits for a triangle id / leaf size and 29 for a node slot
@@ -942,6 +1205,7 @@ int gigl_scene_create(const float* verts, uint32_t n_verts, const uint32_t* tris
     if (!ids_inline && !dtree.ids.empty())
         CREATE_TRY(hipMemcpy(s->d_leaf_ids, dtree.ids.data(), dtree.ids.size() * 4, hipMemcpyHostToDevice));
     s->root = make_uint2(dn[0].w0, dn[0].w1);
+    s->root_rec = make_uint4(dn[0].w0, dn[0].w1, dn[1].w0, dn[1].w1);
     if (!rec.empty()) CREATE_TRY(hipMemcpy(s->d_tris, rec.data(), rec.size() * 4, hipMemcpyHostToDevice));
 #undef CREATE_TRY
     s->box = BoxF{s->tree.box_min[0], s->tree.box_min[1], s->tree.box_min[2],

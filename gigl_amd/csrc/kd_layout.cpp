@@ -201,8 +201,11 @@ void layout_clustered(const KdTreeHost& T, DeviceTree& dt) {
         const uint32_t first_cost = pair_cost(r.host, l0, l1);
         const uint32_t free_dw = back - front;
         // a subtree that fits in one line is kept whole; a larger one starts a line of its own
-        // unless most of a line is still free
-        if (sub[r.host] <= kLine ? sub[r.host] > free_dw : (free_dw < kLine / 2 || first_cost > free_dw)) new_line();
+        // unless nearly all of the current line is still free
+        // measured with tools/layout_sim on the bench batch: distinct node lines per ray 18.96 / 17.24 /
+        // 15.91 / 15.00 / 14.82 / 15.80 for 4 / 8 / 16 / 24 / 28 / 32 dwords
+        constexpr uint32_t min_free = 28;
+        if (sub[r.host] <= kLine ? sub[r.host] > free_dw : (free_dw < min_free || first_cost > free_dw)) new_line();
         heap.push(r);
         deferred.clear();
         while (!heap.empty()) {
@@ -264,7 +267,275 @@ void layout_clustered(const KdTreeHost& T, DeviceTree& dt) {
     std::memcpy(dt.slots.data(), W.data(), W.size() * 4);
 }
 
+// Triple layout (see kd_layout.h).  Lines of 8 units (16 B each): records grow from the front of a
+// line in blocks of 2 or 4 (the grandchildren of one record), leaf records and id arrays from the
+// back; what does not fit beside its record goes to lines of its own at the end of the buffer.
+bool layout_triples(const KdTreeHost& T, DeviceTree& dt) {
+    constexpr uint32_t kLineU = 8;
+    dt.ids_inline = true;
+    dt.triples = true;
+    dt.slots.clear();
+    dt.ids.clear();
+    const std::vector<KdNode>& H = T.nodes;
+    if (dt.slot_of_host) dt.slot_of_host->assign(H.size(), 0u);
+    if (dt.list_dw_of_host) dt.list_dw_of_host->assign(H.size(), ~0u);
+    std::vector<uint32_t> W(4 * kLineU, 0u);
+    bool ok = true;
+    auto fill_pad = [&](uint32_t first_unit, uint32_t n_units) {   // unused units read as empty leaf records
+        for (uint32_t u = first_unit; u < first_unit + n_units; ++u) W[4 * u + 3] = 3u;
+    };
+    fill_pad(0, kLineU);
+    auto finish = [&]() {
+        W.resize(W.size() + 4, 0u);
+        dt.slots.resize(W.size() / 2);
+        std::memcpy(dt.slots.data(), W.data(), W.size() * 4);
+        return ok;
+    };
+    auto n_of = [&](uint32_t k) { return H[k].w1 >> 1; };
+    auto id_of = [&](uint32_t k, uint32_t i) { return n_of(k) == 1u ? H[k].w0 : T.leaf_prim_ids[H[k].w0 + i]; };
+    auto ids_units = [](uint32_t n) { return (n + 3u) / 4u; };
+    uint32_t line = 0, front = 2, back = kLineU;   // current line (unit index of its start), unit offsets in it
+    uint32_t ov_line = 0, ov_used = kLineU;           // overflow: shared lines filled front to back
+    auto alloc_aux = [&](uint32_t nu) -> uint32_t {   // from the back of the current line, else the overflow lines
+        if (nu <= back - front) { back -= nu; return line + back; }
+        if (nu <= kLineU - ov_used) { const uint32_t u = ov_line + ov_used; ov_used += nu; return u; }
+        const uint32_t u = (uint32_t)(W.size() / 4);
+        const uint32_t nl = (nu + kLineU - 1) / kLineU;
+        W.resize(W.size() + (size_t)4 * kLineU * nl, 0u);
+        fill_pad(u, nl * kLineU);
+        if (nu % kLineU) { ov_line = u + (nl - 1) * kLineU; ov_used = nu % kLineU; }
+        return u;
+    };
+    auto write_ids = [&](uint32_t u, uint32_t k) {
+        const uint32_t n = n_of(k);
+        for (uint32_t i = 0; i < n; ++i) W[4 * u + i] = id_of(k, i);
+        for (uint32_t i = n; i < 4 * ids_units(n); ++i) W[4 * u + i] = 0u;
+    };
+    auto write_leaf_record = [&](uint32_t u, uint32_t k) {
+        const uint32_t n = n_of(k);
+        if (n >= (1u << 30)) ok = false;
+        W[4 * u] = W[4 * u + 1] = W[4 * u + 2] = 0u;
+        W[4 * u + 3] = 3u | (n << 2);
+        if (n <= 3u) {
+            for (uint32_t i = 0; i < n; ++i) W[4 * u + i] = id_of(k, i);
+        } else {
+            const uint32_t a = alloc_aux(ids_units(n));
+            W[4 * u] = a;
+            write_ids(a, k);
+            if (dt.list_dw_of_host) (*dt.list_dw_of_host)[k] = 4 * a;
+        }
+    };
+    auto leaf_payload = [&](uint32_t k) -> uint32_t {   // a leaf at a child position
+        const uint32_t n = n_of(k);
+        if (n == 0u) return 0u;
+        if (n == 1u) { if (H[k].w0 >= (1u << 30)) ok = false; return (H[k].w0 << 2) | 1u; }
+        const uint32_t u = alloc_aux(1);
+        if (u >= (1u << 30)) ok = false;
+        write_leaf_record(u, k);
+        if (dt.list_dw_of_host && n <= 3u) (*dt.list_dw_of_host)[k] = 4 * u;
+        return (u << 2) | 2u;
+    };
+    // record of node k at unit u; returns true if k is interior and has grandchildren to place
+    auto place_record = [&](uint32_t u, uint32_t k) -> bool {
+        if (dt.slot_of_host) (*dt.slot_of_host)[k] = 2 * u;
+        if (is_leaf(H[k])) { write_leaf_record(u, k); return false; }
+        const uint32_t kids[2] = {k + 1u, H[k].w1 >> 3};
+        uint32_t meta = (H[k].w1 >> 1) & 3u;
+        W[4 * u] = H[k].w0;
+        bool more = false;
+        for (int j = 0; j < 2; ++j) {
+            const uint32_t c = kids[j];
+            if (dt.slot_of_host) (*dt.slot_of_host)[c] = 2 * u;
+            if (is_leaf(H[c])) {
+                W[4 * u + 1 + j] = leaf_payload(c);
+                meta |= 3u << (2 + 2 * j);
+            } else {
+                W[4 * u + 1 + j] = H[c].w0;
+                meta |= ((H[c].w1 >> 1) & 3u) << (2 + 2 * j);
+                more = true;
+            }
+        }
+        W[4 * u + 3] = meta;
+        return more;
+    };
+    if (H.empty()) return finish();
+    if (is_leaf(H[0])) { place_record(0, 0); return finish(); }
+
+    const uint32_t n_nodes = (uint32_t)H.size();
+    auto aux_of = [&](uint32_t g) -> uint32_t {   // units a record of node g wants beside it
+        if (is_leaf(H[g])) return n_of(g) > 3u ? ids_units(n_of(g)) : 0u;
+        uint32_t a = 0;
+        const uint32_t kids[2] = {g + 1u, H[g].w1 >> 3};
+        for (uint32_t c : kids)
+            if (is_leaf(H[c]) && n_of(c) >= 2u) a += 1u + (n_of(c) > 3u ? ids_units(n_of(c)) : 0u);
+        return a;
+    };
+    auto block_of = [&](uint32_t k, uint32_t g[4]) -> uint32_t {   // the grandchildren of interior node k
+        uint32_t n = 0;
+        const uint32_t kids[2] = {k + 1u, H[k].w1 >> 3};
+        for (uint32_t c : kids)
+            if (!is_leaf(H[c])) { g[n++] = c + 1u; g[n++] = H[c].w1 >> 3; }
+        return n;
+    };
+    // units of everything below an interior record node (saturating); only filled at record positions
+    std::vector<uint32_t> sub(n_nodes, 0u);
+    {
+        std::vector<uint8_t> is_rec(n_nodes, 0);
+        is_rec[0] = 1;
+        for (uint32_t k = 0; k < n_nodes; ++k) {
+            if (!is_rec[k] || is_leaf(H[k])) continue;
+            uint32_t g[4];
+            const uint32_t n = block_of(k, g);
+            for (uint32_t i = 0; i < n; ++i) is_rec[g[i]] = 1;
+        }
+        for (uint32_t k = n_nodes; k-- > 0;) {
+            if (!is_rec[k] || is_leaf(H[k])) continue;
+            uint32_t g[4];
+            const uint32_t n = block_of(k, g);
+            uint64_t s = n;
+            for (uint32_t i = 0; i < n; ++i) s += aux_of(g[i]) + sub[g[i]];
+            sub[k] = s > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)s;
+        }
+    }
+    struct Cand { float sa; uint32_t host; uint32_t unit; float b[6]; };
+    struct BySa { bool operator()(const Cand& a, const Cand& b) const { return a.sa < b.sa; } };
+    auto area = [](const float* b) {
+        const float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
+        return dx * dy + dy * dz + dz * dx;
+    };
+    auto clip = [&](float* b, uint32_t parent, int j) {   // cell of child j of interior node `parent`
+        const unsigned axis = (H[parent].w1 >> 1) & 3u;
+        float split;
+        std::memcpy(&split, &H[parent].w0, 4);
+        if (j == 0) b[3 + axis] = split; else b[axis] = split;
+    };
+    std::vector<Cand> roots, deferred;
+    std::priority_queue<Cand, std::vector<Cand>, BySa> heap;
+    {
+        Cand c;
+        c.host = 0; c.unit = 0;
+        for (int a = 0; a < 3; ++a) { c.b[a] = T.box_min[a]; c.b[3 + a] = T.box_max[a]; }
+        c.sa = area(c.b);
+        if (place_record(0, 0)) roots.push_back(c);
+    }
+    auto new_line = [&]() {
+        line = (uint32_t)(W.size() / 4);
+        W.resize(W.size() + (size_t)4 * kLineU, 0u);
+        fill_pad(line, kLineU);
+        front = 0; back = kLineU;
+    };
+    while (!roots.empty()) {
+        const Cand r = roots.back();
+        roots.pop_back();
+        uint32_t g[4];
+        const uint32_t free_u = back - front;
+        constexpr uint32_t min_free_u = 6;   // tools/layout_sim: 18.50 / 18.38 / 17.63 / 18.08 lines per ray for 2 / 4 / 6 / 8
+        if (sub[r.host] <= kLineU ? sub[r.host] > free_u : (free_u < min_free_u || block_of(r.host, g) > free_u)) new_line();
+        heap.push(r);
+        deferred.clear();
+        while (!heap.empty()) {
+            const Cand c = heap.top();
+            heap.pop();
+            const uint32_t n = block_of(c.host, g);
+            if (n > back - front) { deferred.push_back(c); continue; }
+            const uint32_t at = line + front;
+            front += n;
+            if ((at & 1u) || (at >> 1) >= (1u << kTriplePtrBits)) ok = false;
+            W[4 * c.unit + 3] |= (at >> 1) << 6;
+            // which child of c.host each grandchild hangs under, for the cell boxes
+            const uint32_t kids[2] = {c.host + 1u, H[c.host].w1 >> 3};
+            uint32_t idx = 0;
+            for (int j = 0; j < 2; ++j) {
+                if (is_leaf(H[kids[j]])) continue;
+                for (int jj = 0; jj < 2; ++jj, ++idx) {
+                    Cand nx;
+                    nx.host = g[idx]; nx.unit = at + idx;
+                    std::memcpy(nx.b, c.b, sizeof(nx.b));
+                    clip(nx.b, c.host, j);
+                    clip(nx.b, kids[j], jj);
+                    nx.sa = area(nx.b);
+                    if (place_record(nx.unit, nx.host)) heap.push(nx);
+                }
+            }
+        }
+        std::stable_sort(deferred.begin(), deferred.end(), [&](const Cand& a, const Cand& b) {
+            const bool sa_ = sub[a.host] <= kLineU, sb_ = sub[b.host] <= kLineU;
+            if (sa_ != sb_) return sa_;
+            return a.sa > b.sa;
+        });
+        for (size_t i = deferred.size(); i-- > 0;) roots.push_back(deferred[i]);
+    }
+    return finish();
+}
+
+namespace {
+
+bool verify_triples(const KdTreeHost& T, const DeviceTree& D, const char** what) {
+    auto bad = [&](const char* m) { if (what) *what = m; return false; };
+    const std::vector<KdNode>& H = T.nodes;
+    const uint32_t* W = reinterpret_cast<const uint32_t*>(D.slots.data());
+    const size_t n_units = D.slots.size() / 2;
+    if (n_units < 1) return bad("no root record");
+    auto n_of = [&](uint32_t k) { return H[k].w1 >> 1; };
+    auto id_of = [&](uint32_t k, uint32_t i) { return n_of(k) == 1u ? H[k].w0 : T.leaf_prim_ids[H[k].w0 + i]; };
+    auto leaf_record_ok = [&](uint32_t u, uint32_t k) -> bool {
+        if (u >= n_units) return false;
+        const uint32_t n = n_of(k);
+        if (W[4 * u + 3] != (3u | (n << 2))) return false;
+        if (n <= 3u) {
+            for (uint32_t i = 0; i < n; ++i) if (W[4 * u + i] != id_of(k, i)) return false;
+            return true;
+        }
+        const uint32_t a = W[4 * u];
+        if ((size_t)a + (n + 3u) / 4u > n_units) return false;
+        for (uint32_t i = 0; i < n; ++i) if (W[4 * a + i] != id_of(k, i)) return false;
+        return true;
+    };
+    if (H.empty()) return W[3] == 3u ? true : bad("empty tree must be an empty leaf record");
+    struct It { uint32_t host, unit; };
+    std::vector<It> st(1, It{0u, 0u});
+    size_t seen = 0;
+    while (!st.empty()) {
+        const It it = st.back();
+        st.pop_back();
+        ++seen;
+        if (it.unit >= n_units) return bad("record out of range");
+        const KdNode& h = H[it.host];
+        const uint32_t* r = W + 4 * (size_t)it.unit;
+        if (is_leaf(h)) {
+            if (!leaf_record_ok(it.unit, it.host)) return bad("leaf record");
+            continue;
+        }
+        if ((r[3] & 3u) != ((h.w1 >> 1) & 3u)) return bad("axis of a record");
+        if (r[0] != h.w0) return bad("split of a record");
+        const uint32_t kids[2] = {it.host + 1u, h.w1 >> 3};
+        uint32_t next = (r[3] >> 6) * 2u;
+        for (int j = 0; j < 2; ++j) {
+            const KdNode& c = H[kids[j]];
+            const uint32_t type = (r[3] >> (2 + 2 * j)) & 3u, slot = r[1 + j];
+            ++seen;
+            if (is_leaf(c)) {
+                if (type != 3u) return bad("child leaf type");
+                const uint32_t n = c.w1 >> 1, kind = slot & 3u;
+                if (n == 0u ? slot != 0u : n == 1u ? (kind != 1u || (slot >> 2) != c.w0)
+                                                   : (kind != 2u || !leaf_record_ok(slot >> 2, kids[j])))
+                    return bad("child leaf payload");
+            } else {
+                if (type != ((c.w1 >> 1) & 3u)) return bad("child axis");
+                if (slot != c.w0) return bad("child split");
+                st.push_back(It{c.w1 >> 3, next + 1u});
+                st.push_back(It{kids[j] + 1u, next});
+                next += 2u;
+            }
+        }
+    }
+    return seen == H.size() ? true : bad("node count");
+}
+
+}  // namespace
+
 bool layout_verify(const KdTreeHost& T, const DeviceTree& D, const char** what) {
+    if (D.triples) return verify_triples(T, D, what);
     auto bad = [&](const char* m) { if (what) *what = m; return false; };
     const std::vector<KdNode>& H = T.nodes;
     const std::vector<KdNode>& S = D.slots;

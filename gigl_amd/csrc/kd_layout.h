@@ -22,12 +22,29 @@ namespace gigl {
 
 constexpr uint32_t kDevLeafBit = 0x80000000u, kDevLeafPayload = 0x1FFFFFFFu;
 
+// Triple layout (layout_triples): 16-byte records, one per node at an even depth below the root.
+//   interior record of node N with children A (bottom), B (top):
+//     x = split_N, y = slot of A, z = slot of B (split if interior, else leaf payload)
+//     w = axis_N | type_A << 2 | type_B << 4 | ptr << 6      (type: 0-2 axis, 3 leaf)
+//     ptr * 2 = unit (16 B) index of the block holding the records of A's children (if A is
+//     interior) followed by those of B's children (if B is interior)
+//   leaf payload in a slot: kind (bits 0-1) 0 empty | 1 one prim, id = payload >> 2
+//                           | 2 list, leaf record unit = payload >> 2
+//   leaf record (a leaf at an even depth, or the list of a child-position leaf):
+//     w = 3 | n << 2;  n <= 3: x, y, z = ids;  n > 3: x = unit index of the id array (dwords,
+//     padded to an even count, read 8 bytes at a time)
+// One 16-byte load serves two levels of the descent.
+constexpr uint32_t kTriplePtrBits = 26;
+
 struct DeviceTree {
     std::vector<KdNode> slots;          // 8-byte slots: nodes (and, clustered layout, inline id lists)
     bool ids_inline = false;            // kind-3 leaves index `slots` (as uint32) instead of `ids`
     std::vector<uint32_t> ids;          // level layout: the id lists, each padded to an even length
     // optional diagnostics (filled when non-null on entry): device slot of every host node
     std::vector<uint32_t>* slot_of_host = nullptr;
+    // triple layout diagnostics: dword address of the extra record / id array a leaf reads (~0: none)
+    std::vector<uint32_t>* list_dw_of_host = nullptr;
+    bool triples = false;               // slots hold the triple layout (two slots per record)
 };
 
 // Level layout: treelets of `levels` breadth-first levels of child pairs that never straddle a
@@ -39,6 +56,10 @@ void layout_levels(const KdTreeHost& T, int levels, DeviceTree& out);
 // crosses the parent's cell crosses the child's), together with the id lists of the leaves it
 // holds.  Subtrees that fit in what is left of a line are kept whole.
 void layout_clustered(const KdTreeHost& T, DeviceTree& out);
+
+// Triple layout, clustered into 128-byte lines like layout_clustered.  Returns false if the tree
+// does not fit the encoding (more than 2 GB of records, ids beyond 2^30); the caller falls back.
+bool layout_triples(const KdTreeHost& T, DeviceTree& out);
 
 // Walks the host tree and the device tree side by side: same splits, axes and child order, and at
 // every leaf the same primitives in the same order.  Returns false and a message at the first

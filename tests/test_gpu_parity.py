@@ -133,7 +133,7 @@ def test_launch_options_do_not_change_results(s16, stack_lds, refill, any_atomic
         occ = s16["gpu"].trace(ro, rd, is_vis_ray=True)
         assert np.array_equal(occ.astype(bool), want["tri_id"] != rt.GIGL_MISS)
     finally:
-        rt.set_option("stack_lds", 12)
+        rt.set_option("stack_lds", 8)
         rt.set_option("refill_thresh", 32)
         rt.set_option("any_atomic", -1)
         rt.set_option("t_exit", 16)
@@ -141,6 +141,38 @@ def test_launch_options_do_not_change_results(s16, stack_lds, refill, any_atomic
         rt.set_option("sort_bits", 6)
         rt.set_option("guided", 4)
         rt.set_option("chunk", 256)
+
+
+@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("stack_lds", [8, 16])
+def test_device_layouts_do_not_change_results(cornell, cornell_cam, oracle_cornell, layout, stack_lds):
+    """Level treelets, clustered lines and triple records (two levels per load, its own kernel) hold the
+    same tree: closest-hit records and occlusion bits are the oracle's under every layout, with the
+    LDS stack short enough to spill (8) and not."""
+    V, T = synth.tessellate(cornell["verts"], cornell["tris"], 16)
+    ora = O.OracleScene(V, T, **S.KD_PARAMS)
+    try:
+        rt.set_option("layout", layout)
+        rt.set_option("stack_lds", stack_lds)
+        g = rt.Scene(V, T, device=0, **S.KD_PARAMS)
+        gc = rt.Scene(cornell["verts"], cornell["tris"], device=0, **S.KD_PARAMS)
+        ro, rd = synth.bounce_rays(V, T, 100_003, 0xBEEF02)
+        want = ora.trace_closest(ro, rd, n_threads=4)
+        assert_hits_equal(g.trace(ro, rd), want)
+        for any_atomic in (0, 1):
+            rt.set_option("any_atomic", any_atomic)
+            assert np.array_equal(g.trace(ro, rd, is_vis_ray=True), ora.trace_any(ro, rd, n_threads=4))
+        po, pd = O.primary_rays(cornell_cam, 1024, 0, 1024 * 1024)
+        sel = slice(0, 1024 * 1024, 7)
+        assert_hits_equal(gc.trace(po[sel], pd[sel]), oracle_cornell.trace_closest(po[sel], pd[sel], n_threads=4))
+        assert np.array_equal(gc.trace(po[sel], pd[sel], is_vis_ray=True),
+                              oracle_cornell.trace_any(po[sel], pd[sel], n_threads=4))
+        g.close()
+        gc.close()
+    finally:
+        rt.set_option("layout", 1)
+        rt.set_option("stack_lds", 8)
+        rt.set_option("any_atomic", -1)
 
 
 def test_edge_cases(gpu_cornell, oracle_cornell):

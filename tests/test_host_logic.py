@@ -81,7 +81,7 @@ def test_device_layouts_keep_the_tree(cornell):
     for V, T in scenes:
         for params in (S.KD_PARAMS, dict(inters_cost=10, trav_cost=1, max_depth=4, min_num_prims=2, empty_bonus=0.25)):
             ps = rt.Scene(V, T, device=-1, **params)
-            sizes = [ps.check_layout(0, lv) for lv in (1, 2, 3, 4, 5)] + [ps.check_layout(1)]
+            sizes = [ps.check_layout(0, lv) for lv in (1, 2, 3, 4, 5)] + [ps.check_layout(1), ps.check_layout(2)]
             assert all(b >= 16 for b in sizes)
             ps.close()
 

@@ -118,7 +118,7 @@ struct Tracer {
                 uint32_t id = H[node].w0;
                 if (n >= 2) {
                     id = T.leaf_prim_ids[H[node].w0 + i];
-                    if (n >= 3) ev->push_back(Ev{1u, i, node});
+                    ev->push_back(Ev{1u, i, node});
                 }
                 ev->push_back(Ev{2u, 0u, id});
                 hit = tri(id, o, d, tmin, tmax, best) || hit;
@@ -145,6 +145,7 @@ struct Report { double node, ids, tri, all, node_all, ids_all, tri_all; size_t b
 
 // abstract layouts: only a line number per host node (id lists are taken to share the leaf's line)
 static const std::vector<uint32_t>* g_abstract_lines = nullptr;
+static const std::vector<uint32_t>* g_list_dw = nullptr;   // triple layout: dword address of a leaf's extra record
 static size_t g_abstract_bytes = 0;
 
 static Report price(const gigl::KdTreeHost& T, const gigl::DeviceTree& D, const std::vector<uint32_t>& slot_of,
@@ -155,10 +156,16 @@ static Report price(const gigl::KdTreeHost& T, const gigl::DeviceTree& D, const 
         if (g_abstract_lines && e.kind != 2u) return (*g_abstract_lines)[e.idx];
         if (e.kind == 0u) return ((uint64_t)slot_of[e.idx] * 8u) >> 7;
         if (e.kind == 1u) {
+            if (D.triples) {
+                const uint32_t dw = (*g_list_dw)[e.idx];
+                return dw == ~0u ? (((uint64_t)slot_of[e.idx] * 8u) >> 7) : (((uint64_t)dw * 4u) >> 7);
+            }
             if (D.ids_inline) {
+                if ((T.nodes[e.idx].w1 >> 1) < 3u) return ((uint64_t)slot_of[e.idx] * 8u) >> 7;
                 const uint32_t dw = D.slots[slot_of[e.idx]].w0 + e.pos;
                 return ((uint64_t)dw * 4u) >> 7;
             }
+            if ((T.nodes[e.idx].w1 >> 1) < 3u) return ((uint64_t)slot_of[e.idx] * 8u) >> 7;   // ids in the node
             return (1ull << 40) | (((uint64_t)(T.nodes[e.idx].w0 + e.pos) * 4u) >> 7);
         }
         return (2ull << 40) | (TL.addr(e.idx) >> 7);
@@ -238,7 +245,6 @@ int main(int argc, char** argv) {
             acc += g_push_depth[k];
         }
         printf("\n");
-        if (argc > 3) return 0;
     }
 
     TriLayout tl64;   // 64-byte records in id order (round 1)
@@ -280,9 +286,26 @@ int main(int argc, char** argv) {
         D.slot_of_host = &slot_of;
         gigl::layout_clustered(T, D);
         show("clustered, tris 64B id order", price(T, D, slot_of, tl64, ev, ray_begin, hot));
-        show("clustered, tris 64B leaf order", price(T, D, slot_of, tl_dfs, ev, ray_begin, hot));
-        show("clustered, tris 40B leaf order", price(T, D, slot_of, tl40, ev, ray_begin, hot));
+        TriLayout tl40id = tl64;
+        tl40id.rec_bytes = 40; tl40id.per_line = 3;
+        show("clustered, tris 40B id order", price(T, D, slot_of, tl40id, ev, ray_begin, hot));
+        TriLayout tl32id = tl64;   // hypothetical 32-byte records
+        tl32id.rec_bytes = 32; tl32id.per_line = 4;
+        show("clustered, tris 32B id order", price(T, D, slot_of, tl32id, ev, ray_begin, hot));
     }
+    {
+        gigl::DeviceTree D;
+        std::vector<uint32_t> list_dw;
+        D.slot_of_host = &slot_of;
+        D.list_dw_of_host = &list_dw;
+        const bool fits = gigl::layout_triples(T, D);
+        const char* what = nullptr;
+        const bool same = gigl::layout_verify(T, D, &what);
+        printf("triples: fits %d, verify %d %s\n", (int)fits, (int)same, what ? what : "");
+        g_list_dw = &list_dw;
+        show("triples, tris 64B id order", price(T, D, slot_of, tl64, ev, ray_begin, hot));
+    }
+    if (argc > 3) return 0;
     // ---- abstract layouts: what would denser node encodings buy? ----
     const std::vector<KdNode>& H = T.nodes;
     std::vector<uint32_t> lines(H.size(), 0u);

@@ -6,7 +6,7 @@ for tag in sys.argv[1:]:
     for f in sorted(glob.glob('gpurun_out/%s/*/*/*counter_collection.csv' % tag)):
         acc = collections.defaultdict(lambda: collections.defaultdict(float))
         for r in csv.DictReader(open(f)):
-            if 'trace_kernel' in r['Kernel_Name']:
+            if 'trace_kernel' in r['Kernel_Name'] or 'trace3_kernel' in r['Kernel_Name']:
                 acc[r['Counter_Name']][r['Dispatch_Id']] += float(r['Counter_Value'])
         for k, d in acc.items():
             v = list(d.values())
