@@ -191,11 +191,17 @@ def main():
         k_ms = float(np.mean(kern_ms))
         # per GPU: one launch sequence over this rank's rays (None: a non-default workload without counters)
         achieved = bytes_per_ray * n / (k_ms * 1e-3) / 1e9 if bytes_per_ray is not None else None
+        layout = 2
+        for kv in args.opt:
+            if kv.startswith("layout="):
+                layout = int(kv.split("=")[1])
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tp) and default_workload:
             try:
-                traffic = json.load(open(tp)).get("trace_closest_hbm_bytes_per_launch")
+                tj = json.load(open(tp))
+                if tj.get("layout") == layout:   # counters of the kernel that ran
+                    traffic = tj.get("trace_closest_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
@@ -212,7 +218,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": None if achieved is None else round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel": "trace_kernel<closest>", "kernel_ms": round(k_ms, 4),
+                         "kernel": "trace3_kernel<closest>" if layout == 2 else "trace_kernel<closest>",
+                         "kernel_ms": round(k_ms, 4),
                          "algorithmic_bytes_per_ray": None if bytes_per_ray is None else round(bytes_per_ray, 2),
                          "mean_nodes_visited": mean_nodes, "mean_triangle_tests": mean_tris},
             "cpu_baseline": cpu,

@@ -470,7 +470,7 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
 // a child inside a record: rec.x = its slot (split or leaf payload), rec.y = type | block unit << 3.
 // Stack entries are (t_split, w0, w1): w1 bit 2 clear = a lvl-1 node (w0 = slot, w1 = rec.y), set = a
 // record still to be loaded (unit = w1 >> 3).
-template <bool ANY, int GEN, int STACK_N, int BLOCK>
+template <bool ANY, int GEN, int STACK_N, int BLOCK, bool STATS = false>
 __global__ void __launch_bounds__(BLOCK) trace3_kernel(const TraceParams P) {
     __shared__ uint2 s_stack[STACK_N * BLOCK];     // (t_split, w1)
     __shared__ unsigned s_stack0[STACK_N * BLOCK]; // w0
@@ -535,6 +535,10 @@ __global__ void __launch_bounds__(BLOCK) trace3_kernel(const TraceParams P) {
         have_ray = false;
     };
 
+    // STATS build only (tools/sweep.py stats=1): wave-level round counts and lane-level work counts
+    const unsigned long long st_t0 = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    unsigned st_rounds = 0, st_t_iters = 0, st_t_lanes = 0, st_l_rounds = 0, st_l_lanes = 0, st_refills = 0,
+             st_refill_lanes = 0, st_rays_lanes = 0;
     uint4 rec = make_uint4(0u, 0u, 0u, 3u);   // a lane without a ray holds an empty leaf record
     unsigned lvl = 0, leaf_i = 0;
     const int t_exit = P.t_exit;
@@ -562,7 +566,9 @@ __global__ void __launch_bounds__(BLOCK) trace3_kernel(const TraceParams P) {
     for (;;) {
         const unsigned long long idle = __ballot(!have_ray);
         const int n_idle = __popcll(idle);
+        if (STATS) { ++st_rounds; st_rays_lanes += 64 - n_idle; }
         if (n_idle >= P.refill_thresh && !pool_empty) {
+            if (STATS) { ++st_refills; st_refill_lanes += n_idle; }
             if (group_mode) {
                 const unsigned long long m = __ballot(occ);
                 if (group_base != kMiss && lane == 0) P.bits[group_base >> 6] = m;
@@ -622,6 +628,7 @@ __global__ void __launch_bounds__(BLOCK) trace3_kernel(const TraceParams P) {
             const bool is_t = ((lvl == 0u ? rec.w : rec.y) & 3u) != 3u;
             const unsigned long long m_t = __ballot(is_t);
             if (m_t == 0ull) break;
+            if (STATS) { ++st_t_iters; st_t_lanes += __popcll(m_t); }
             if (is_t) {
                 if (lvl == 0u) {   // a node with both children in its record: no load
                     const Step s = decide(rec.w & 3u, __uint_as_float(rec.x));
@@ -661,6 +668,10 @@ __global__ void __launch_bounds__(BLOCK) trace3_kernel(const TraceParams P) {
             }
             const unsigned n_prims = rec.w >> 2;
             bool any_done = false;
+            if (STATS) {   // L rounds that test triangles, and the lanes that do
+                const unsigned long long m_l = __ballot(leaf_i < n_prims);
+                if (m_l) { ++st_l_rounds; st_l_lanes += __popcll(m_l); }
+            }
             if (leaf_i < n_prims) {
                 unsigned id0, id1;
                 const bool two = leaf_i + 1 < n_prims;
@@ -715,6 +726,21 @@ __global__ void __launch_bounds__(BLOCK) trace3_kernel(const TraceParams P) {
     if (group_mode) {
         const unsigned long long m = __ballot(occ);
         if (group_base != kMiss && lane == 0) P.bits[group_base >> 6] = m;
+    }
+    if (STATS && lane == 0 && P.stats) {
+        atomicAdd(P.stats + 0, (unsigned long long)st_rounds);
+        atomicAdd(P.stats + 1, (unsigned long long)st_t_iters);
+        atomicAdd(P.stats + 2, (unsigned long long)st_t_lanes);
+        atomicAdd(P.stats + 3, (unsigned long long)st_l_rounds);
+        atomicAdd(P.stats + 4, (unsigned long long)st_l_lanes);
+        atomicAdd(P.stats + 5, (unsigned long long)st_refills);
+        atomicAdd(P.stats + 6, (unsigned long long)st_refill_lanes);
+        atomicAdd(P.stats + 7, (unsigned long long)st_rays_lanes);
+        const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
+        atomicMax(P.stats + 8, ~st_t0);
+        atomicMax(P.stats + 9, t_end);
+        atomicAdd(P.stats + 10, t_end);
+        atomicAdd(P.stats + 11, 1ull);
     }
 }
 
@@ -862,8 +888,9 @@ struct Options {
                               // cost more than the 1.7 ms the regrouped traversal saves
     int sort_bits = 6;        // cells per axis = 2^sort_bits (4..6)
     int treelet_levels = 3;   // read at gigl_scene_create: levels of child pairs per cache-line treelet (1..5)
-    int layout = 1;           // read at gigl_scene_create: 0 level treelets + separate id lists, 1 clustered lines
-                              // with the id lists in their leaves' lines (kd_layout.h)
+    int layout = 2;           // read at gigl_scene_create (kd_layout.h): 0 level treelets + separate id lists,
+                              // 1 clustered lines with the id lists in their leaves' lines, 2 triple records
+                              // (two levels per load, trace3_kernel; falls back to 1 beyond its encoding)
 };
 Options g_opt;
 std::mutex g_opt_mu;
@@ -872,11 +899,13 @@ unsigned long long g_last_stats[12] = {0};
 template <bool ANY, int GEN, int STACK_N>
 int launch_trace_t(const gigl_scene* s, TraceParams& P, const Options& opt, hipStream_t st) {
     auto kern = s->triples ? trace3_kernel<ANY, GEN, STACK_N, kBlock> : trace_kernel<ANY, GEN, STACK_N, kBlock>;
-    if (!s->triples && !ANY && GEN == 0 && STACK_N == 12 && opt.stats) kern = trace_kernel<ANY, GEN, 12, kBlock, true>;
+    // instrumented builds: explicit-ray closest-hit with the default LDS stack only
+    const bool stats = !ANY && GEN == 0 && STACK_N == 8 && opt.stats;
+    if (stats) kern = s->triples ? trace3_kernel<ANY, GEN, 8, kBlock, true> : trace_kernel<ANY, GEN, 8, kBlock, true>;
     int per_cu = opt.blocks_per_cu;
     if (per_cu <= 0) {
         static int cached[3] = {0, 0, 0};  // per instantiation; [1] is the instrumented build, [2] the triple-layout kernel
-        int& c = cached[s->triples ? 2 : (!ANY && GEN == 0 && STACK_N == 12 && opt.stats) ? 1 : 0];
+        int& c = cached[stats ? 1 : s->triples ? 2 : 0];
         if (c <= 0) {
             int q = 0;
             HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, kern, kBlock, 0));
@@ -906,9 +935,7 @@ int launch_trace_t(const gigl_scene* s, TraceParams& P, const Options& opt, hipS
     P.guided = opt.guided > 0 ? grid * (kBlock / 64u) * (unsigned)opt.guided : 0u;
     if ((uint64_t)P.n < 2ull * P.guided * P.chunk) P.guided = 0u;
     P.stats = nullptr;
-    if (!s->triples && !ANY && GEN == 0 && STACK_N == 12 && opt.stats) {
-        P.stats = (unsigned long long*)((char*)ws + 128);
-    }
+    if (stats) P.stats = (unsigned long long*)((char*)ws + 128);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, st, P);
     hipError_t le = hipGetLastError();
     if (P.stats && le == hipSuccess) {  // diagnostic path: synchronous read-back

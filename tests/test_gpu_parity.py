@@ -170,7 +170,7 @@ def test_device_layouts_do_not_change_results(cornell, cornell_cam, oracle_corne
         g.close()
         gc.close()
     finally:
-        rt.set_option("layout", 1)
+        rt.set_option("layout", 2)
         rt.set_option("stack_lds", 8)
         rt.set_option("any_atomic", -1)
 

@@ -18,7 +18,7 @@ out = {}
 for f in glob.glob(os.path.join(src, "*", "*", "*_counter_collection.csv")):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "trace_kernel" in r["Kernel_Name"]:
+        if "trace_kernel" in r["Kernel_Name"] or "trace3_kernel" in r["Kernel_Name"]:
             agg[(r["Kernel_Name"], r["Counter_Name"])].append(float(r["Counter_Value"]))
     for (k, c), v in agg.items():
         out[c] = {"per_launch_mean": sum(v) / len(v), "launches": len(v), "kernel": k.replace("(anonymous namespace)::", "")}

@@ -54,7 +54,7 @@ def main():
             scenes[layout] = rt.Scene(V, T, device=0, **S.KD_PARAMS)
             print("layout", layout, "device bytes", scenes[layout].stats().device_bytes, flush=True)
         return scenes[layout]
-    scene = scene_for(1)
+    scene = scene_for(2)
     n = 1 << a.rays_log2
     ro, rd = synth.bounce_rays(V, T, n, synth.RAY_SEED_16M)
     d_o, d_d = torch.from_numpy(ro).to(dev), torch.from_numpy(rd).to(dev)
@@ -75,7 +75,7 @@ def main():
     for r in range(a.rounds + 1):
         for v in a.variants:
             opts = dict(defaults)
-            pseudo = {"sorted": 0, "any": 0, "stats": 0, "layout": 1}
+            pseudo = {"sorted": 0, "any": 0, "stats": 0, "layout": 2}
             for kv in v.split(","):
                 if not kv or kv == "base":
                     continue
