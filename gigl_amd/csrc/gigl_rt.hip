@@ -17,11 +17,13 @@
 // counter (one atomic per `chunk` rays), one ray per lane, and refills idle lanes (found with a
 // ballot) once enough of them have retired, so long-tailed rays do not hold 63 idle lanes hostage.
 // Lanes run a two-state machine (Traversing / at a Leaf, see trace_kernel).  The per-lane traversal
-// stack holds (t_split, node) pairs — t_min/t_max are rebuilt from them on pop — with the first
-// STACK_N entries in LDS (lane-interleaved, conflict-free ds_read/write_b64) and the rare deeper
-// entries (0.04 % of pushes on the 1M-triangle scene) in a global spill area.
-// Device data layout: flatten_nodes() (pair-addressed nodes in 128-byte treelets) and the 64-byte
-// triangle records built in gigl_scene_create().
+// stack holds (t_split, far child's node words) — t_min/t_max are rebuilt from t_split on pop, and
+// a pop costs no global load — with the first STACK_N entries in LDS (lane-interleaved, conflict
+// free) and the deeper entries (2 % of pushes on the 1M-triangle scene with 8 in LDS) in a global
+// spill area.
+// Device data layout: kd_layout.cpp (triple records for trace3_kernel, pair-addressed nodes in
+// clustered 128-byte lines or level treelets for trace_kernel) and the 64-byte triangle records
+// built in gigl_scene_create().
 #include "gigl_internal.h"
 #include "kd_layout.h"
 
@@ -1193,7 +1195,7 @@ int gigl_scene_create(const float* verts, uint32_t n_verts, const uint32_t* tris
         uint64_t thr = UINT64_MAX;
         (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr);
     }
-    // ---- device node array: same topology, cache-line treelet order (see flatten_nodes) ----
+    // ---- device tree: same topology, re-addressed for the kernels (kd_layout.h) ----
     gigl::DeviceTree dtree;
     if (layout == 2 && !gigl::layout_triples(s->tree, dtree)) layout = 1;   // beyond the record encoding: fall back
     if (layout == 1) { dtree = gigl::DeviceTree(); gigl::layout_clustered(s->tree, dtree); }
