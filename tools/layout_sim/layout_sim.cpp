@@ -47,6 +47,9 @@ static float eps_of(float t) {
 }
 
 static uint64_t g_push_depth[64];   // pushes by stack depth before the push
+// leaf visits: [arrived by descent / by pop][odd / even depth][empty / with prims]
+static uint64_t g_leaf_visit[2][2][2];
+static uint64_t g_near_empty_both[2];   // "both" steps whose near child is an empty leaf, by depth parity of the child
 
 struct Tracer {
     const gigl::KdTreeHost& T;
@@ -86,7 +89,8 @@ struct Tracer {
         if (!(entr <= exit && entr < tmax && exit > tmin)) return;
         tmin = std::max(tmin, entr - eps_of(entr));
         tmax = std::min(tmax, exit + eps_of(exit));
-        struct St { float tmin, tmax; uint32_t id; } stack[64];
+        struct St { float tmin, tmax; uint32_t id; int depth; } stack[64];
+        int depth = 0, by_pop = 0;
         int sp = 0;
         uint32_t node = 0;
         float best = FLT_MAX;
@@ -106,13 +110,17 @@ struct Tracer {
                 else if (ts < tmin) node = second;
                 else {
                     ++g_push_depth[sp];
-                    stack[sp++] = St{ts - eps_of(ts), tmax, second};
+                    stack[sp++] = St{ts - eps_of(ts), tmax, second, depth + 1};
                     node = first;
                     tmax = ts + eps_of(ts);
+                    if ((H[node].w1 & 1u) && (H[node].w1 >> 1) == 0u) ++g_near_empty_both[(depth + 1) & 1];
                 }
+                ++depth;
+                by_pop = 0;
                 ev->push_back(Ev{0u, 0u, node});
             }
             const uint32_t n = H[node].w1 >> 1;
+            ++g_leaf_visit[by_pop][depth & 1][n ? 1 : 0];
             bool hit = false;
             for (uint32_t i = 0; i < n; ++i) {
                 uint32_t id = H[node].w0;
@@ -126,7 +134,7 @@ struct Tracer {
             if (hit) break;
             if (sp == 0) break;
             --sp;
-            node = stack[sp].id; tmin = stack[sp].tmin; tmax = stack[sp].tmax;
+            node = stack[sp].id; tmin = stack[sp].tmin; tmax = stack[sp].tmax; depth = stack[sp].depth; by_pop = 1;
         }
     }
 };
@@ -245,6 +253,12 @@ int main(int argc, char** argv) {
             acc += g_push_depth[k];
         }
         printf("\n");
+        for (int bp = 0; bp < 2; ++bp)
+            for (int par = 0; par < 2; ++par)
+                printf("leaf visits/ray arrived by %s at %s depth: empty %.2f, with prims %.2f\n", bp ? "pop    " : "descent",
+                       par ? "odd " : "even", (double)g_leaf_visit[bp][par][0] / nr, (double)g_leaf_visit[bp][par][1] / nr);
+        printf("both-steps/ray whose near child is an empty leaf: odd depth %.2f, even depth %.2f\n",
+               (double)g_near_empty_both[1] / nr, (double)g_near_empty_both[0] / nr);
     }
 
     TriLayout tl64;   // 64-byte records in id order (round 1)
