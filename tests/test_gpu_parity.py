@@ -175,6 +175,28 @@ def test_device_layouts_do_not_change_results(cornell, cornell_cam, oracle_corne
         rt.set_option("any_atomic", -1)
 
 
+@pytest.mark.parametrize("layout", [1, 2])
+@pytest.mark.parametrize("params", [dict(inters_cost=10, trav_cost=1, max_depth=4, min_num_prims=2, empty_bonus=0.25),
+                                    dict(inters_cost=80, trav_cost=1, max_depth=-1, min_num_prims=1, empty_bonus=0.5),
+                                    dict(inters_cost=1, trav_cost=10, max_depth=12, min_num_prims=9, empty_bonus=0.0)])
+def test_other_tree_shapes(cornell, layout, params):
+    """Shallow trees with hundreds of prims per leaf (id arrays longer than a cache line, the overflow
+    area of the layouts), deep trees from the automatic depth rule, and fat leaves: same hits as the oracle."""
+    V, T = synth.tessellate(cornell["verts"], cornell["tris"], 12)
+    ora = O.OracleScene(V, T, **params)
+    try:
+        rt.set_option("layout", layout)
+        g = rt.Scene(V, T, device=0, **params)
+        assert g.check_layout(layout) > 0
+        ro, rd = synth.bounce_rays(V, T, 40_001, 0xF00D03)
+        want = ora.trace_closest(ro, rd, n_threads=4)
+        assert_hits_equal(g.trace(ro, rd), want)
+        assert np.array_equal(g.trace(ro, rd, is_vis_ray=True), ora.trace_any(ro, rd, n_threads=4))
+        g.close()
+    finally:
+        rt.set_option("layout", 2)
+
+
 def test_edge_cases(gpu_cornell, oracle_cornell):
     # empty batch
     assert len(gpu_cornell.trace(np.zeros((0, 4), np.float32), np.zeros((0, 4), np.float32))) == 0
