@@ -82,7 +82,11 @@ def main():
                 k, val = kv.split("=")
                 (pseudo if k in pseudo else opts)[k] = int(val)
             for k, val in opts.items():
-                rt.set_option(k, val)
+                try:
+                    rt.set_option(k, val)
+                except rt.GiglError:
+                    if k not in defaults:   # an older library under GIGL_RT_LIB may lack a default knob
+                        raise
             rt.set_option("stats", pseudo["stats"])
             o, d = presorted(pseudo["sorted"]) if pseudo["sorted"] else (d_o, d_d)
             scene = scene_for(pseudo["layout"])
