@@ -175,14 +175,16 @@ __device__ __forceinline__ bool tri_test(const TriRec& T, unsigned id, const Ray
 // Spill-area accesses are opaque to the optimizer on purpose: merged with the LDS path they
 // turn every stack access into a flat_* instruction.
 typedef unsigned spill_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void spill_store(uint4* p, unsigned a, unsigned b, unsigned c) {
-    spill_t e; e.x = a; e.y = b; e.z = c; e.w = 0u;
+// A spilled entry also keeps the t_max it was pushed with (the fourth dword is free), so popping it
+// is one load: entries in LDS rebuild t_max from the entry below them instead.
+__device__ __forceinline__ void spill_store(uint4* p, unsigned a, unsigned b, unsigned c, unsigned d) {
+    spill_t e; e.x = a; e.y = b; e.z = c; e.w = d;
     asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(e) : "memory");
 }
-__device__ __forceinline__ void spill_load(const uint4* p, unsigned& a, unsigned& b, unsigned& c) {
+__device__ __forceinline__ void spill_load(const uint4* p, unsigned& a, unsigned& b, unsigned& c, unsigned& d) {
     spill_t e;
     asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(e) : "v"(p) : "memory");
-    a = e.x; b = e.y; c = e.z;
+    a = e.x; b = e.y; c = e.z; d = e.w;
 }
 
 // Device node encoding (same topology and numbering as the reference's m_nodes, KdTree.h:22-65):
@@ -224,30 +226,36 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
     bool occ = false;
     const bool group_mode = ANY && !P.any_atomic;
 
-    auto push = [&](float t_split, unsigned w0, unsigned w1) {
+    auto push = [&](float t_split, unsigned w0, unsigned w1) {   // call before r.tmax shrinks
         ++sp;
         if (STACK_N >= 32 || sp < STACK_N) {
             my_stack[sp * BLOCK] = make_uint2(__float_as_uint(t_split), w1);
             my_stack0[sp * BLOCK] = w0;
-        } else spill_store(my_spill + (size_t)(sp - STACK_N) * P.spill_stride, __float_as_uint(t_split), w0, w1);
+        } else spill_store(my_spill + (size_t)(sp - STACK_N) * P.spill_stride, __float_as_uint(t_split), w0, w1,
+                           __float_as_uint(r.tmax));
     };
-    auto peek_t = [&](int k) -> float {   // t_split of entry k
-        if (STACK_N >= 32 || k < STACK_N) return __uint_as_float(my_stack[k * BLOCK].x);
-        unsigned a, b, c;
-        spill_load(my_spill + (size_t)(k - STACK_N) * P.spill_stride, a, b, c);
-        return __uint_as_float(a);
-    };
-    auto peek = [&](int k, float& t_split, uint2& words) {
-        if (STACK_N >= 32 || k < STACK_N) {
-            const uint2 e = my_stack[k * BLOCK];
-            t_split = __uint_as_float(e.x);
-            words = make_uint2(my_stack0[k * BLOCK], e.y);
+    // pop, KdTree.hpp:334-339: the entry's node words, and the ray's range as the reference stored it
+    auto pop = [&](unsigned& w0, unsigned& w1) {
+        float ts;
+        if (STACK_N >= 32 || sp < STACK_N) {
+            const uint2 e = my_stack[sp * BLOCK];
+            ts = __uint_as_float(e.x);
+            w0 = my_stack0[sp * BLOCK];
+            w1 = e.y;
+            if (sp > 0) {
+                const float tb = __uint_as_float(my_stack[(sp - 1) * BLOCK].x);
+                r.tmax = tb + eps_of(tb);
+            } else {
+                r.tmax = root_tmax;
+            }
         } else {
-            unsigned a, b, c;
-            spill_load(my_spill + (size_t)(k - STACK_N) * P.spill_stride, a, b, c);
-            t_split = __uint_as_float(a);
-            words = make_uint2(b, c);
+            unsigned a, d;
+            spill_load(my_spill + (size_t)(sp - STACK_N) * P.spill_stride, a, w0, w1, d);
+            ts = __uint_as_float(a);
+            r.tmax = __uint_as_float(d);
         }
+        r.tmin = ts - eps_of(ts);
+        --sp;
     };
     auto finish = [&](bool hit) {
         if (ANY) {
@@ -421,17 +429,8 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
                     // t_split - eps(t_split) (:305) and the stored t_max is always the t_max set when
                     // the entry below was pushed, t_split' + eps(t_split') (:310), or the root t_max
                     // for the bottom entry, so both are rebuilt from the stored t_split values.
-                    float ts;
                     uint2 far_words;
-                    peek(sp, ts, far_words);
-                    r.tmin = ts - eps_of(ts);
-                    if (sp > 0) {
-                        const float tb = peek_t(sp - 1);
-                        r.tmax = tb + eps_of(tb);
-                    } else {
-                        r.tmax = root_tmax;
-                    }
-                    --sp;
+                    pop(far_words.x, far_words.y);
                     if (best_t < r.tmin) finish(false);  // KdTree.hpp:280
                     else { nd = far_words; leaf_i = 0; }
                 } else {
@@ -499,30 +498,36 @@ __global__ void __launch_bounds__(BLOCK) trace3_kernel(const TraceParams P) {
     bool occ = false;
     const bool group_mode = ANY && !P.any_atomic;
 
-    auto push = [&](float t_split, unsigned w0, unsigned w1) {
+    auto push = [&](float t_split, unsigned w0, unsigned w1) {   // call before r.tmax shrinks
         ++sp;
         if (STACK_N >= 32 || sp < STACK_N) {
             my_stack[sp * BLOCK] = make_uint2(__float_as_uint(t_split), w1);
             my_stack0[sp * BLOCK] = w0;
-        } else spill_store(my_spill + (size_t)(sp - STACK_N) * P.spill_stride, __float_as_uint(t_split), w0, w1);
+        } else spill_store(my_spill + (size_t)(sp - STACK_N) * P.spill_stride, __float_as_uint(t_split), w0, w1,
+                           __float_as_uint(r.tmax));
     };
-    auto peek_t = [&](int k) -> float {
-        if (STACK_N >= 32 || k < STACK_N) return __uint_as_float(my_stack[k * BLOCK].x);
-        unsigned a, b, c;
-        spill_load(my_spill + (size_t)(k - STACK_N) * P.spill_stride, a, b, c);
-        return __uint_as_float(a);
-    };
-    auto peek = [&](int k, float& t_split, unsigned& w0, unsigned& w1) {
-        if (STACK_N >= 32 || k < STACK_N) {
-            const uint2 e = my_stack[k * BLOCK];
-            t_split = __uint_as_float(e.x);
-            w0 = my_stack0[k * BLOCK];
+    // pop, KdTree.hpp:334-339: the entry's node words, and the ray's range as the reference stored it
+    auto pop = [&](unsigned& w0, unsigned& w1) {
+        float ts;
+        if (STACK_N >= 32 || sp < STACK_N) {
+            const uint2 e = my_stack[sp * BLOCK];
+            ts = __uint_as_float(e.x);
+            w0 = my_stack0[sp * BLOCK];
             w1 = e.y;
+            if (sp > 0) {
+                const float tb = __uint_as_float(my_stack[(sp - 1) * BLOCK].x);
+                r.tmax = tb + eps_of(tb);
+            } else {
+                r.tmax = root_tmax;
+            }
         } else {
-            unsigned a;
-            spill_load(my_spill + (size_t)(k - STACK_N) * P.spill_stride, a, w0, w1);
-            t_split = __uint_as_float(a);
+            unsigned a, d;
+            spill_load(my_spill + (size_t)(sp - STACK_N) * P.spill_stride, a, w0, w1, d);
+            ts = __uint_as_float(a);
+            r.tmax = __uint_as_float(d);
         }
+        r.tmin = ts - eps_of(ts);
+        --sp;
     };
     auto finish = [&](bool hit) {
         if (ANY) {
@@ -699,17 +704,8 @@ __global__ void __launch_bounds__(BLOCK) trace3_kernel(const TraceParams P) {
                     finish(true);
                     rec.w = 3u; lvl = 0u;
                 } else if (sp >= 0) {
-                    float ts;
                     unsigned w0, w1;
-                    peek(sp, ts, w0, w1);
-                    r.tmin = ts - eps_of(ts);
-                    if (sp > 0) {
-                        const float tb = peek_t(sp - 1);
-                        r.tmax = tb + eps_of(tb);
-                    } else {
-                        r.tmax = root_tmax;
-                    }
-                    --sp;
+                    pop(w0, w1);
                     if (best_t < r.tmin) {   // KdTree.hpp:280
                         finish(false);
                         rec.w = 3u; lvl = 0u;
