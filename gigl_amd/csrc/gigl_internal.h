@@ -5,24 +5,16 @@
 #include <hip/hip_runtime.h>
 
 // A/B switches kept from tuning (tools/sweep.py over builds, same device, interleaved): the
-// branch-free child-order predicate is worth 1-3 %; the branch-free triangle test costs 10 VGPRs,
-// drops the kernel from 6 to 5 waves/SIMD and loses 4-10 % on coherent batches.  GIGL_EARLY_PAIR requests
-// both children of a node before the step is decided (+14 % on coherent batches, +1.5 % on the
-// incoherent bench batch, which is bound by the chip's L2-miss rate instead).
+// branch-free triangle test costs 10 VGPRs, drops the kernel from 6 to 5 waves/SIMD and loses 4-10 %
+// on coherent batches; the nontemporal hint on ray loads and hit stores is worth 1.5-3.7 %.
 #ifndef GIGL_BRANCHLESS_TRI
 #define GIGL_BRANCHLESS_TRI 0
-#endif
-#ifndef GIGL_BRANCHLESS_STEP
-#define GIGL_BRANCHLESS_STEP 1
 #endif
 #ifndef GIGL_STREAM_HINT
 #define GIGL_STREAM_HINT 1
 #endif
 
-#ifndef GIGL_COND_T1
-#define GIGL_COND_T1 1
-#endif
-
+#include <atomic>
 #include <cfloat>
 #include <chrono>
 #include <cmath>
@@ -139,6 +131,8 @@ struct TraceParams {
     unsigned long long* bits;
     unsigned long long* stats;   // STATS build only: 12 counters
     float2* ranges;              // optional: the ray's (t_min, t_max) as KdTree::intersect leaves them
+    float4* hit_tri;             // optional, with ranges: the first 48 bytes of the hit triangle's record per ray
+    unsigned reset_counter;      // single-wave launches only: the wave zeroes the work counter on exit
     const unsigned* perm;        // optional (GEN 0): work item i traces ray perm[i] (ray regrouping)
 };
 
@@ -279,8 +273,14 @@ struct gigl_scene {
     float4* d_tris = nullptr;
     gd::BoxF box;
     gigl_tree_stats stats;
-    // staging for gigl_trace_one
-    float4* d_one = nullptr;   // 2 float4 in, 1 uint4 out
+    int layout = 2;                // device layout in use (kd_layout.h): 0, 1 or 2 (2 may fall back to 1 at create)
+    // gigl_trace_one: pinned, device-mapped staging (7 float4: ray in, hit record, range and hit
+    // triangle out), a persistent workspace for its single-wave launch and a stream of its own, so a
+    // call is one memcpy-free launch and one stream synchronisation
+    float4* h_one = nullptr;       // host address
+    float4* d_one = nullptr;       // the same memory as the device sees it
+    void* one_ws = nullptr;        // 256-byte counter block (kept at zero by the kernel) + one wave's spill area
+    hipStream_t one_stream = nullptr;
     std::mutex one_mu;
 };
 

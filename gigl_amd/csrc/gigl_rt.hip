@@ -21,8 +21,8 @@
 // a pop costs no global load — with the first STACK_N entries in LDS (lane-interleaved, conflict
 // free) and the deeper entries (2 % of pushes on the 1M-triangle scene with 8 in LDS) in a global
 // spill area.
-// Device data layout: kd_layout.cpp (triple records for trace3_kernel, pair-addressed nodes in
-// clustered 128-byte lines or level treelets for trace_kernel) and the 64-byte triangle records
+// Device data layout: kd_layout.cpp (triple records, or pair-addressed nodes in clustered 128-byte
+// lines or level treelets; trace_kernel walks either) and the 64-byte triangle records
 // built in gigl_scene_create().
 #include "gigl_internal.h"
 #include "kd_layout.h"
@@ -177,9 +177,12 @@ __device__ __forceinline__ bool tri_test(const TriRec& T, unsigned id, const Ray
 typedef unsigned spill_t __attribute__((ext_vector_type(4)));
 // A spilled entry also keeps the t_max it was pushed with (the fourth dword is free), so popping it
 // is one load: entries in LDS rebuild t_max from the entry below them instead.
+// The s_nop covers the wait states gfx9 needs between a VMEM store of more than 64 bits and a VALU
+// write to its data registers: the compiler's hazard recognizer does not look inside inline asm, and
+// `e` is dead (free for the next VALU result) as soon as the asm ends.
 __device__ __forceinline__ void spill_store(uint4* p, unsigned a, unsigned b, unsigned c, unsigned d) {
     spill_t e; e.x = a; e.y = b; e.z = c; e.w = d;
-    asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(e) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(e) : "memory");
 }
 __device__ __forceinline__ void spill_load(const uint4* p, unsigned& a, unsigned& b, unsigned& c, unsigned& d) {
     spill_t e;
@@ -187,19 +190,36 @@ __device__ __forceinline__ void spill_load(const uint4* p, unsigned& a, unsigned
     a = e.x; b = e.y; c = e.z; d = e.w;
 }
 
-// Device node encoding (same topology and numbering as the reference's m_nodes, KdTree.h:22-65):
-//   interior: w0 = split_pos, w1 = slot of the children pair << 2 | axis (bottom child first;
-//             slots follow flatten_nodes' treelet order, not the reference's depth-first order)
+// ---- the traversal kernel ---------------------------------------------------------------------
+// One kernel body for both device layouts (kd_layout.h); the wave pool, the refill, the stack, the
+// T/L phase scheduling, the triangle rounds, the outputs and the instrumented build are shared, and
+// only the node step and the leaf decoding differ (`if constexpr (TRIPLES)`).  Per ray the sequence
+// of reference operations (KdTree.hpp:266-347) is the same under either layout.
+//
+// TRIPLES = false: pair-addressed 8-byte nodes (layouts 0 and 1; same topology and numbering as the
+// reference's m_nodes, KdTree.h:22-65):
+//   interior: w0 = split_pos, w1 = slot of the children pair << 2 | axis (bottom child first)
 //   leaf:     w1 bit 31 = 1 (so "still descending" is one signed compare), bits 29-30 = kind,
 //             bits 0-28 = payload
 //             kind 0: empty          kind 1: one prim, w0 = id
 //             kind 2: two prims, w0 = id0, payload = id1 (saves the m_leaf_prim_ids round trip)
 //             kind 3: n >= 3 prims, w0 = offset into leaf_ids, payload = n
-// A lane without a ray always holds a leaf word, so the T-phase test needs no have_ray term.
-template <bool ANY, int GEN, int STACK_N, int BLOCK, bool STATS = false>
+//   An interior step requests both children (one aligned 16-byte pair) before it decides which one
+//   to enter, so the decision's arithmetic overlaps the memory round trip.
+//
+// TRIPLES = true: triple records (layout 2).  One 16-byte record holds a node at an even depth and
+// both of its children, so one load serves two levels of the descent: half the per-lane loads and
+// half the dependent round trips.  Lane state: lvl 0 = `rec` is the record of the current node
+// (interior record, or leaf record when (rec.w & 3) == 3); lvl 1 = the current node is a child
+// inside a record: rec.x = its slot (split or leaf payload), rec.y = type | block unit << 3.
+// Stack entries are (t_split, w0, w1): w1 bit 2 clear = a lvl-1 node (w0 = slot, w1 = rec.y), set =
+// a record still to be loaded (unit = w1 >> 3).
+//
+// A lane without a ray always holds a leaf, so the T-phase test needs no have_ray term.
+template <bool TRIPLES, bool ANY, int GEN, int STACK_N, int BLOCK, bool STATS = false>
 __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
-    // stack entry = (t_split, the far child's two node words): the child pair is in registers when
-    // the entry is pushed, so a pop costs no global load
+    // stack entry = (t_split, the far child's two words): the far child is in registers when the
+    // entry is pushed, so a pop costs no global load (pairs) or at most the record's (triples)
     __shared__ uint2 s_stack[STACK_N * BLOCK];     // (t_split, w1)
     __shared__ unsigned s_stack0[STACK_N * BLOCK]; // w0
     __shared__ float s_eps[kEpsTable];
@@ -211,6 +231,7 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
     uint2* const my_stack = s_stack + tid;
     unsigned* const my_stack0 = s_stack0 + tid;
     uint4* const my_spill = P.spill + ((size_t)blockIdx.x * BLOCK + tid);
+    const uint4* __restrict__ recs = P.recs;
 
     RayReg r;
     float root_tmax = 0.0f;
@@ -225,7 +246,15 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
     unsigned group_base = kMiss;
     bool occ = false;
     const bool group_mode = ANY && !P.any_atomic;
+    // node state (see above); a lane without a ray holds an empty leaf
+    uint2 nd = make_uint2(0u, kLeafBit);
+    uint4 rec = make_uint4(0u, 0u, 0u, 3u);
+    unsigned lvl = 0, leaf_i = 0;
 
+    auto descending = [&]() -> bool {
+        if constexpr (TRIPLES) return ((lvl == 0u ? rec.w : rec.y) & 3u) != 3u;
+        else return (int)nd.y >= 0;
+    };
     auto push = [&](float t_split, unsigned w0, unsigned w1) {   // call before r.tmax shrinks
         ++sp;
         if (STACK_N >= 32 || sp < STACK_N) {
@@ -234,7 +263,10 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
         } else spill_store(my_spill + (size_t)(sp - STACK_N) * P.spill_stride, __float_as_uint(t_split), w0, w1,
                            __float_as_uint(r.tmax));
     };
-    // pop, KdTree.hpp:334-339: the entry's node words, and the ray's range as the reference stored it
+    // pop, KdTree.hpp:334-339.  The reference stores (t_min, t_max, id); t_min is t_split - eps(t_split)
+    // (:305) and the stored t_max is always the t_max set when the entry below was pushed,
+    // t_split' + eps(t_split') (:310), or the root t_max for the bottom entry, so both are rebuilt
+    // from the stored t_split values.
     auto pop = [&](unsigned& w0, unsigned& w1) {
         float ts;
         if (STACK_N >= 32 || sp < STACK_N) {
@@ -265,24 +297,52 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
             stream_store(P.hits + ray_idx, hit ? make_uint4(best_id, __float_as_uint(best_t), __float_as_uint(best_u),
                                                             __float_as_uint(best_v))
                                                : make_uint4(kMiss, __float_as_uint(FLT_MAX), 0u, 0u));
-            if (P.ranges) P.ranges[ray_idx] = make_float2(r.tmin, r.tmax);
+            if (P.ranges) {   // gigl_trace_one: the ray's range as KdTree::intersect leaves it, and the hit triangle
+                P.ranges[ray_idx] = make_float2(r.tmin, r.tmax);
+                if (P.hit_tri && hit) {
+                    const float4* t = P.tris + kTriStride * (size_t)best_id;
+                    P.hit_tri[3 * ray_idx] = t[0]; P.hit_tri[3 * ray_idx + 1] = t[1]; P.hit_tri[3 * ray_idx + 2] = t[2];
+                }
+            }
         }
         have_ray = false;
+        if constexpr (TRIPLES) { rec.w = 3u; lvl = 0u; }   // pairs: nd already is the leaf the ray ended in
     };
 
-    // Per-lane state machine.  A lane with a ray is either Traversing (nd is an interior node) or
-    // at a Leaf (nd is a leaf, leaf_i = next primitive to test).  Every round of the outer loop runs
-    // a T-phase (interior steps, repeated while at least t_exit lanes are still descending, so a
-    // few stragglers do not stall the lanes already waiting at leaves) and an L-phase (one pair of
-    // triangle tests per lane at a leaf).  Per ray the sequence of operations is the reference's.
-    uint2 nd = make_uint2(0u, kLeafBit);
-    unsigned leaf_i = 0;
-    const int t_exit = P.t_exit;
-    // STATS build only: wave-level round counts and lane-level work counts (tools/sweep.py stats=1)
+    // one interior step, KdTree.hpp:288-311: which child first, which children at all
+    struct Step { float t_split; bool bottom_first, both, take_top; };
+    auto decide = [&](unsigned axis, float split) -> Step {
+        const float oa = sel3(axis, r.ox, r.oy, r.oz);
+        const float ia = sel3(axis, r.ix, r.iy, r.iz);
+        // KdTree.hpp:289-291: below the plane, or on it and not heading up.  The direction only
+        // matters for an origin exactly on the plane, so it is selected on that (wave-uniform,
+        // rarely taken) branch only.
+        bool bottom_first = oa < split;
+        if (__ballot(oa == split) != 0ull) {
+            asm volatile("" ::: "memory");  // keeps this a real branch (else it is if-converted)
+            bottom_first = bottom_first | ((oa == split) & (sel3(axis, r.dx, r.dy, r.dz) <= 0.0f));
+        }
+        Step s;
+        s.t_split = (split - oa) * ia;
+        const bool only_first = (s.t_split > r.tmax) | (s.t_split <= 0.0f);
+        const bool only_second = s.t_split < r.tmin;
+        s.bottom_first = bottom_first;
+        s.both = !(only_first | only_second);
+        s.take_top = bottom_first == (!only_first & only_second);   // the child entered now is the top one
+        return s;
+    };
+
+    // STATS build only (tools/sweep.py stats=1): wave-level round counts and lane-level work counts
     const unsigned long long st_t0 = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;
     unsigned st_rounds = 0, st_t_iters = 0, st_t_lanes = 0, st_l_rounds = 0, st_l_lanes = 0, st_refills = 0,
              st_refill_lanes = 0, st_rays_lanes = 0;
+    const int t_exit = P.t_exit;
 
+    // Per-lane state machine.  A lane with a ray is either Traversing (at an interior node) or at a
+    // Leaf (leaf_i = next primitive to test).  Every round of the outer loop runs a T-phase (interior
+    // steps, repeated while at least t_exit lanes are still descending, so a few stragglers do not
+    // stall the lanes already waiting at leaves) and an L-phase (one pair of triangle tests per lane
+    // at a leaf).
     for (;;) {
         const unsigned long long idle = __ballot(!have_ray);
         const int n_idle = __popcll(idle);
@@ -339,8 +399,11 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
                                 go = !(best_t < r.tmin);  // KdTree.hpp:280
                             }
                         }
-                        if (go) { have_ray = true; nd = P.root; sp = -1; leaf_i = 0; }
-                        else finish(false);
+                        if (go) {
+                            have_ray = true; sp = -1; leaf_i = 0;
+                            if constexpr (TRIPLES) { rec = P.root_rec; lvl = 0; }
+                            else nd = P.root;
+                        } else finish(false);
                     }
                 }
                 pool_next = __builtin_amdgcn_readfirstlane(pool_next + take);
@@ -352,68 +415,93 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
         }
         // ---- T-phase: KdTree.hpp:284-311 ----
         for (;;) {
-            const bool is_t = (int)nd.y >= 0;
+            const bool is_t = descending();
             const unsigned long long m_t = __ballot(is_t);
             if (m_t == 0ull) break;
             if (STATS) { ++st_t_iters; st_t_lanes += __popcll(m_t); }
             if (is_t) {
-                const unsigned axis = nd.y & 3u;
-                const unsigned pair = nd.y >> 2;   // slot of the bottom child; the top child is the next slot
-                // both children (one aligned 16-byte pair) are requested before the step is decided,
-                // so the decision's arithmetic overlaps the memory round trip
-                const uint4 kids = *reinterpret_cast<const uint4*>(P.nodes + pair);
-                const float split = __uint_as_float(nd.x);
-                const float oa = sel3(axis, r.ox, r.oy, r.oz);
-                const float ia = sel3(axis, r.ix, r.iy, r.iz);
-                // KdTree.hpp:289-291: below the plane, or on it and not heading up.  The direction
-                // only matters for an origin exactly on the plane, so it is selected on that
-                // (wave-uniform, rarely taken) branch only.
-                bool bottom_first = oa < split;
-                if (__ballot(oa == split) != 0ull) {
-                    asm volatile("" ::: "memory");  // keeps this a real branch (else it is if-converted)
-                    bottom_first = bottom_first | ((oa == split) & (sel3(axis, r.dx, r.dy, r.dz) <= 0.0f));
+                if constexpr (TRIPLES) {   // up to two levels and exactly one record load per lane and iteration
+                    if (lvl == 0u) {   // a node with both children in its record: no load
+                        const Step s = decide(rec.w & 3u, __uint_as_float(rec.x));
+                        const unsigned type_a = (rec.w >> 2) & 3u, type_b = (rec.w >> 4) & 3u;
+                        const unsigned blk = (rec.w >> 6) << 1;                    // unit of A's children
+                        const unsigned blk_b = blk + (type_a != 3u ? 2u : 0u);     // unit of B's children
+                        const unsigned desc_a = type_a | (blk << 3), desc_b = type_b | (blk_b << 3);
+                        if (s.both) {      // the far child waits on the stack
+                            push(s.t_split, s.bottom_first ? rec.z : rec.y, s.bottom_first ? desc_b : desc_a);
+                            r.tmax = s.t_split + eps_of(s.t_split);
+                        }
+                        rec.x = s.take_top ? rec.z : rec.y;
+                        rec.y = s.take_top ? desc_b : desc_a;
+                        lvl = 1u;
+                    }
+                    if ((rec.y & 3u) != 3u) {   // a child inside a record: its children are records of their own
+                        const Step s = decide(rec.y & 3u, __uint_as_float(rec.x));
+                        const unsigned blk = rec.y >> 3;
+                        if (s.both) {
+                            push(s.t_split, 0u, 4u | ((blk + (s.bottom_first ? 1u : 0u)) << 3));
+                            r.tmax = s.t_split + eps_of(s.t_split);
+                        }
+                        rec = recs[blk + (s.take_top ? 1u : 0u)];
+                        lvl = 0u;
+                    }
+                } else {
+                    // slot of the bottom child; the top child is the next slot
+                    const uint4 kids = *reinterpret_cast<const uint4*>(P.nodes + (nd.y >> 2));
+                    const Step s = decide(nd.y & 3u, __uint_as_float(nd.x));
+                    if (s.both) {  // both children: the far one waits on the stack
+                        push(s.t_split, s.bottom_first ? kids.z : kids.x, s.bottom_first ? kids.w : kids.y);
+                        r.tmax = s.t_split + eps_of(s.t_split);
+                    }
+                    nd = s.take_top ? make_uint2(kids.z, kids.w) : make_uint2(kids.x, kids.y);
                 }
-                const float t_split = (split - oa) * ia;
-                const bool only_first = (t_split > r.tmax) | (t_split <= 0.0f);
-                const bool only_second = t_split < r.tmin;
-                const bool take_second = !only_first & only_second;
-                // first = bottom_first ? pair : pair + 1, second = the other slot
-                if (!(only_first | only_second)) {  // both children: the far one waits on the stack
-                    push(t_split, bottom_first ? kids.z : kids.x, bottom_first ? kids.w : kids.y);
-                    r.tmax = t_split + eps_of(t_split);
-                }
-                nd = (bottom_first == take_second) ? make_uint2(kids.z, kids.w) : make_uint2(kids.x, kids.y);
             }
             if ((int)__popcll(m_t) < t_exit) break;
         }
         // ---- L-phase: KdTree.hpp:312-343.  Prims are tested in m_leaf_prim_ids order, two per
         // round; both triangles' loads are issued before the first test. ----
-        if (STATS) {
-            const unsigned long long m_l = __ballot(have_ray && (int)nd.y < 0);
-            if (m_l) { ++st_l_rounds; st_l_lanes += __popcll(m_l); }
-        }
-        if (have_ray && (int)nd.y < 0) {
-            const unsigned kind = (nd.y >> 29) & 3u;
-            const unsigned n_prims = kind == 3u ? (nd.y & kLeafPayload) : kind;
+        if (have_ray && !descending()) {
+            unsigned n_prims;
+            if constexpr (TRIPLES) {
+                if (lvl == 1u) {   // a leaf inside a record: its payload names the prims
+                    const unsigned payload = rec.x, kind = payload & 3u;
+                    if (kind == 2u) rec = recs[payload >> 2];
+                    else rec = make_uint4(payload >> 2, 0u, 0u, kind == 1u ? (3u | (1u << 2)) : 3u);
+                    lvl = 0u;
+                }
+                n_prims = rec.w >> 2;
+            } else {
+                const unsigned kind = (nd.y >> 29) & 3u;
+                n_prims = kind == 3u ? (nd.y & kLeafPayload) : kind;
+            }
             bool any_done = false;
+            if (STATS) {   // L rounds that test triangles, and the lanes that do
+                const unsigned long long m_l = __ballot(leaf_i < n_prims);
+                if (m_l) { ++st_l_rounds; st_l_lanes += __popcll(m_l); }
+            }
             if (leaf_i < n_prims) {
                 unsigned id0, id1;
                 const bool two = leaf_i + 1 < n_prims;
-                if (kind == 3u) {
-                    // lists are 8-byte aligned and padded to an even length (kd_layout.h)
-                    const uint2 two_ids = *reinterpret_cast<const uint2*>(P.leaf_ids + nd.x + leaf_i);
-                    id0 = two_ids.x; id1 = two_ids.y;
+                if constexpr (TRIPLES) {
+                    if (n_prims <= 3u) {
+                        id0 = leaf_i == 0u ? rec.x : rec.z;
+                        id1 = rec.y;
+                    } else {
+                        const uint2 two_ids = reinterpret_cast<const uint2*>(recs + rec.x)[leaf_i >> 1];
+                        id0 = two_ids.x; id1 = two_ids.y;
+                    }
                 } else {
-                    id0 = nd.x;
-                    id1 = nd.y & kLeafPayload;
+                    if (n_prims >= 3u) {
+                        // lists are 8-byte aligned and padded to an even length (kd_layout.h)
+                        const uint2 two_ids = *reinterpret_cast<const uint2*>(P.leaf_ids + nd.x + leaf_i);
+                        id0 = two_ids.x; id1 = two_ids.y;
+                    } else {
+                        id0 = nd.x;
+                        id1 = nd.y & kLeafPayload;
+                    }
                 }
                 const TriRec t0 = load_tri(P.tris, id0);
-#if GIGL_COND_T1
-                TriRec t1 = t0;
-                if (two) t1 = load_tri(P.tris, id1);   // a lane's loads are what the memory pipeline counts
-#else
                 const TriRec t1 = load_tri(P.tris, two ? id1 : id0);
-#endif
                 bool hit = tri_test(t0, id0, r, best_t, best_u, best_v, best_id);
                 if (!(ANY && hit) && two) hit = tri_test(t1, id1, r, best_t, best_u, best_v, best_id) || hit;
                 any_done = ANY && hit;
@@ -425,14 +513,19 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
                 if (best_id != kMiss) {
                     finish(true);  // closest hit inside this leaf's cell: KdTree.hpp:320,332
                 } else if (sp >= 0) {
-                    // ---- pop: KdTree.hpp:334-339.  The reference stores (t_min, t_max, id); t_min is
-                    // t_split - eps(t_split) (:305) and the stored t_max is always the t_max set when
-                    // the entry below was pushed, t_split' + eps(t_split') (:310), or the root t_max
-                    // for the bottom entry, so both are rebuilt from the stored t_split values.
-                    uint2 far_words;
-                    pop(far_words.x, far_words.y);
-                    if (best_t < r.tmin) finish(false);  // KdTree.hpp:280
-                    else { nd = far_words; leaf_i = 0; }
+                    unsigned w0, w1;
+                    pop(w0, w1);
+                    if (best_t < r.tmin) {   // KdTree.hpp:280
+                        finish(false);
+                    } else {
+                        leaf_i = 0;
+                        if constexpr (TRIPLES) {
+                            if (w1 & 4u) { rec = recs[w1 >> 3]; lvl = 0u; }
+                            else { rec.x = w0; rec.y = w1; lvl = 1u; }
+                        } else {
+                            nd = make_uint2(w0, w1);
+                        }
+                    }
                 } else {
                     finish(false);
                 }
@@ -443,6 +536,8 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
         const unsigned long long m = __ballot(occ);
         if (group_base != kMiss && lane == 0) P.bits[group_base >> 6] = m;
     }
+    // a single-wave launch (gigl_trace_one) leaves the work counter at zero for the next one
+    if (P.reset_counter && blockIdx.x == 0 && tid == 0) *P.counter = 0u;
     if (STATS && lane == 0 && P.stats) {
         atomicAdd(P.stats + 0, (unsigned long long)st_rounds);
         atomicAdd(P.stats + 1, (unsigned long long)st_t_iters);
@@ -456,286 +551,6 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
         // launch is (latest end) - (mean end)
         const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
         atomicMax(P.stats + 8, ~st_t0);   // earliest start, complemented (the slot starts at 0)
-        atomicMax(P.stats + 9, t_end);
-        atomicAdd(P.stats + 10, t_end);
-        atomicAdd(P.stats + 11, 1ull);
-    }
-}
-
-// ---- traversal over the triple layout (kd_layout.h: layout_triples) ------------------------------
-// One 16-byte record holds a node at an even depth and both of its children, so one load serves two
-// levels of the descent: half the per-lane loads and half the dependent round trips of trace_kernel.
-// Per ray the sequence of reference operations (KdTree.hpp:266-347) is unchanged; scheduling (wave
-// pool, refill, T/L phases, stack) is trace_kernel's.  Lane state: lvl 0 = `rec` is the record of the
-// current node (interior record, or leaf record when (rec.w & 3) == 3); lvl 1 = the current node is
-// a child inside a record: rec.x = its slot (split or leaf payload), rec.y = type | block unit << 3.
-// Stack entries are (t_split, w0, w1): w1 bit 2 clear = a lvl-1 node (w0 = slot, w1 = rec.y), set = a
-// record still to be loaded (unit = w1 >> 3).
-template <bool ANY, int GEN, int STACK_N, int BLOCK, bool STATS = false>
-__global__ void __launch_bounds__(BLOCK) trace3_kernel(const TraceParams P) {
-    __shared__ uint2 s_stack[STACK_N * BLOCK];     // (t_split, w1)
-    __shared__ unsigned s_stack0[STACK_N * BLOCK]; // w0
-    __shared__ float s_eps[kEpsTable];
-    const unsigned tid = threadIdx.x;
-    const unsigned lane = tid & 63u;
-    for (int i = (int)tid; i < kEpsTable; i += BLOCK) s_eps[i] = eps_from_exp(i - kEpsBias + 1);
-    __syncthreads();
-    auto eps_of = [&](float t) { return s_eps[(unsigned)(__builtin_amdgcn_frexp_expf(t) + kEpsBias)]; };
-    uint2* const my_stack = s_stack + tid;
-    unsigned* const my_stack0 = s_stack0 + tid;
-    uint4* const my_spill = P.spill + ((size_t)blockIdx.x * BLOCK + tid);
-    const uint4* __restrict__ recs = P.recs;
-
-    RayReg r;
-    float root_tmax = 0.0f;
-    float best_t = FLT_MAX, best_u = 0.0f, best_v = 0.0f;
-    unsigned best_id = kMiss;
-    unsigned ray_idx = 0;
-    int sp = -1;
-    bool have_ray = false, pool_empty = false;
-    unsigned pool_next = 0, pool_end = 0, last_base = 0;
-    unsigned group_base = kMiss;
-    bool occ = false;
-    const bool group_mode = ANY && !P.any_atomic;
-
-    auto push = [&](float t_split, unsigned w0, unsigned w1) {   // call before r.tmax shrinks
-        ++sp;
-        if (STACK_N >= 32 || sp < STACK_N) {
-            my_stack[sp * BLOCK] = make_uint2(__float_as_uint(t_split), w1);
-            my_stack0[sp * BLOCK] = w0;
-        } else spill_store(my_spill + (size_t)(sp - STACK_N) * P.spill_stride, __float_as_uint(t_split), w0, w1,
-                           __float_as_uint(r.tmax));
-    };
-    // pop, KdTree.hpp:334-339: the entry's node words, and the ray's range as the reference stored it
-    auto pop = [&](unsigned& w0, unsigned& w1) {
-        float ts;
-        if (STACK_N >= 32 || sp < STACK_N) {
-            const uint2 e = my_stack[sp * BLOCK];
-            ts = __uint_as_float(e.x);
-            w0 = my_stack0[sp * BLOCK];
-            w1 = e.y;
-            if (sp > 0) {
-                const float tb = __uint_as_float(my_stack[(sp - 1) * BLOCK].x);
-                r.tmax = tb + eps_of(tb);
-            } else {
-                r.tmax = root_tmax;
-            }
-        } else {
-            unsigned a, d;
-            spill_load(my_spill + (size_t)(sp - STACK_N) * P.spill_stride, a, w0, w1, d);
-            ts = __uint_as_float(a);
-            r.tmax = __uint_as_float(d);
-        }
-        r.tmin = ts - eps_of(ts);
-        --sp;
-    };
-    auto finish = [&](bool hit) {
-        if (ANY) {
-            if (group_mode) occ = hit;
-            else if (hit) atomicOr(((unsigned*)P.bits) + (ray_idx >> 5), 1u << (ray_idx & 31u));
-        } else {
-            stream_store(P.hits + ray_idx, hit ? make_uint4(best_id, __float_as_uint(best_t), __float_as_uint(best_u),
-                                                            __float_as_uint(best_v))
-                                               : make_uint4(kMiss, __float_as_uint(FLT_MAX), 0u, 0u));
-            if (P.ranges) P.ranges[ray_idx] = make_float2(r.tmin, r.tmax);
-        }
-        have_ray = false;
-    };
-
-    // STATS build only (tools/sweep.py stats=1): wave-level round counts and lane-level work counts
-    const unsigned long long st_t0 = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;
-    unsigned st_rounds = 0, st_t_iters = 0, st_t_lanes = 0, st_l_rounds = 0, st_l_lanes = 0, st_refills = 0,
-             st_refill_lanes = 0, st_rays_lanes = 0;
-    uint4 rec = make_uint4(0u, 0u, 0u, 3u);   // a lane without a ray holds an empty leaf record
-    unsigned lvl = 0, leaf_i = 0;
-    const int t_exit = P.t_exit;
-
-    // one interior step, KdTree.hpp:288-311: which child first, which children at all
-    struct Step { float t_split; bool bottom_first, both, take_top; };
-    auto decide = [&](unsigned axis, float split) -> Step {
-        const float oa = sel3(axis, r.ox, r.oy, r.oz);
-        const float ia = sel3(axis, r.ix, r.iy, r.iz);
-        bool bottom_first = oa < split;
-        if (__ballot(oa == split) != 0ull) {
-            asm volatile("" ::: "memory");
-            bottom_first = bottom_first | ((oa == split) & (sel3(axis, r.dx, r.dy, r.dz) <= 0.0f));
-        }
-        Step s;
-        s.t_split = (split - oa) * ia;
-        const bool only_first = (s.t_split > r.tmax) | (s.t_split <= 0.0f);
-        const bool only_second = s.t_split < r.tmin;
-        s.bottom_first = bottom_first;
-        s.both = !(only_first | only_second);
-        s.take_top = bottom_first == (!only_first & only_second);   // the child entered now is the top one
-        return s;
-    };
-
-    for (;;) {
-        const unsigned long long idle = __ballot(!have_ray);
-        const int n_idle = __popcll(idle);
-        if (STATS) { ++st_rounds; st_rays_lanes += 64 - n_idle; }
-        if (n_idle >= P.refill_thresh && !pool_empty) {
-            if (STATS) { ++st_refills; st_refill_lanes += n_idle; }
-            if (group_mode) {
-                const unsigned long long m = __ballot(occ);
-                if (group_base != kMiss && lane == 0) P.bits[group_base >> 6] = m;
-                occ = false;
-                group_base = kMiss;
-            }
-            if (pool_next == pool_end) {
-                unsigned base = 0, take_n = P.chunk;
-                if (P.guided) {
-                    const unsigned rem = last_base < P.n ? P.n - last_base : 0u;
-                    const unsigned g = (rem / P.guided) & ~63u;
-                    take_n = g < 64u ? 64u : (g < P.chunk ? g : P.chunk);
-                }
-                if (lane == 0) base = atomicAdd(P.counter, take_n);
-                base = __builtin_amdgcn_readfirstlane(base);
-                last_base = base;
-                pool_next = base < P.n ? base : P.n;
-                pool_end = (P.n - pool_next) < take_n ? P.n : pool_next + take_n;
-                if (pool_next == pool_end) pool_empty = true;
-            }
-            if (!pool_empty) {
-                const unsigned avail = pool_end - pool_next;
-                const unsigned take = (unsigned)n_idle < avail ? (unsigned)n_idle : avail;
-                if (group_mode) group_base = pool_next;
-                if (!have_ray) {
-                    const unsigned rank = __popcll(idle & ((1ull << lane) - 1ull));
-                    if (rank < take) {
-                        unsigned idx = pool_next + rank;
-                        if (GEN == 0 && P.perm) idx = P.perm[idx];
-                        ray_idx = idx;
-                        best_t = FLT_MAX; best_u = 0.0f; best_v = 0.0f; best_id = kMiss;
-                        bool go = fetch_ray<GEN>(P, idx, r);
-                        if (go) {
-                            float entr, exit;
-                            go = box_intersect(P.box, r, entr, exit);
-                            if (go) {
-                                const float nmin = gmax(r.tmin, entr - eps_of(entr));
-                                const float nmax = gmin(r.tmax, exit + eps_of(exit));
-                                r.tmin = nmin; r.tmax = nmax;
-                                root_tmax = nmax;
-                                go = !(best_t < r.tmin);
-                            }
-                        }
-                        if (go) { have_ray = true; rec = P.root_rec; lvl = 0; sp = -1; leaf_i = 0; }
-                        else finish(false);
-                    }
-                }
-                pool_next = __builtin_amdgcn_readfirstlane(pool_next + take);
-            }
-        }
-        if (__ballot(have_ray) == 0ull) {
-            if (pool_empty) break;
-            continue;
-        }
-        // ---- T-phase: up to two levels and exactly one record load per lane and iteration ----
-        for (;;) {
-            const bool is_t = ((lvl == 0u ? rec.w : rec.y) & 3u) != 3u;
-            const unsigned long long m_t = __ballot(is_t);
-            if (m_t == 0ull) break;
-            if (STATS) { ++st_t_iters; st_t_lanes += __popcll(m_t); }
-            if (is_t) {
-                if (lvl == 0u) {   // a node with both children in its record: no load
-                    const Step s = decide(rec.w & 3u, __uint_as_float(rec.x));
-                    const unsigned type_a = (rec.w >> 2) & 3u, type_b = (rec.w >> 4) & 3u;
-                    const unsigned blk = (rec.w >> 6) << 1;                    // unit of A's children
-                    const unsigned blk_b = blk + (type_a != 3u ? 2u : 0u);     // unit of B's children
-                    const unsigned desc_a = type_a | (blk << 3), desc_b = type_b | (blk_b << 3);
-                    if (s.both) {      // the far child waits on the stack
-                        push(s.t_split, s.bottom_first ? rec.z : rec.y, s.bottom_first ? desc_b : desc_a);
-                        r.tmax = s.t_split + eps_of(s.t_split);
-                    }
-                    rec.x = s.take_top ? rec.z : rec.y;
-                    rec.y = s.take_top ? desc_b : desc_a;
-                    lvl = 1u;
-                }
-                if ((rec.y & 3u) != 3u) {   // a child inside a record: its children are records of their own
-                    const Step s = decide(rec.y & 3u, __uint_as_float(rec.x));
-                    const unsigned blk = rec.y >> 3;
-                    if (s.both) {
-                        push(s.t_split, 0u, 4u | ((blk + (s.bottom_first ? 1u : 0u)) << 3));
-                        r.tmax = s.t_split + eps_of(s.t_split);
-                    }
-                    rec = recs[blk + (s.take_top ? 1u : 0u)];
-                    lvl = 0u;
-                }
-            }
-            if ((int)__popcll(m_t) < t_exit) break;
-        }
-        // ---- L-phase: KdTree.hpp:312-343 ----
-        const bool at_leaf = have_ray && ((lvl == 0u ? rec.w : rec.y) & 3u) == 3u;
-        if (at_leaf) {
-            if (lvl == 1u) {   // a leaf inside a record: its payload names the prims
-                const unsigned payload = rec.x, kind = payload & 3u;
-                if (kind == 2u) rec = recs[payload >> 2];
-                else rec = make_uint4(payload >> 2, 0u, 0u, kind == 1u ? (3u | (1u << 2)) : 3u);
-                lvl = 0u;
-            }
-            const unsigned n_prims = rec.w >> 2;
-            bool any_done = false;
-            if (STATS) {   // L rounds that test triangles, and the lanes that do
-                const unsigned long long m_l = __ballot(leaf_i < n_prims);
-                if (m_l) { ++st_l_rounds; st_l_lanes += __popcll(m_l); }
-            }
-            if (leaf_i < n_prims) {
-                unsigned id0, id1;
-                const bool two = leaf_i + 1 < n_prims;
-                if (n_prims <= 3u) {
-                    id0 = leaf_i == 0u ? rec.x : rec.z;
-                    id1 = rec.y;
-                } else {
-                    const uint2 two_ids = reinterpret_cast<const uint2*>(recs + rec.x)[leaf_i >> 1];
-                    id0 = two_ids.x; id1 = two_ids.y;
-                }
-                const TriRec t0 = load_tri(P.tris, id0);
-                const TriRec t1 = load_tri(P.tris, two ? id1 : id0);
-                bool hit = tri_test(t0, id0, r, best_t, best_u, best_v, best_id);
-                if (!(ANY && hit) && two) hit = tri_test(t1, id1, r, best_t, best_u, best_v, best_id) || hit;
-                any_done = ANY && hit;
-                leaf_i += 2;
-            }
-            if (any_done) {
-                finish(true);
-                rec.w = 3u; lvl = 0u;
-            } else if (leaf_i >= n_prims) {
-                if (best_id != kMiss) {
-                    finish(true);
-                    rec.w = 3u; lvl = 0u;
-                } else if (sp >= 0) {
-                    unsigned w0, w1;
-                    pop(w0, w1);
-                    if (best_t < r.tmin) {   // KdTree.hpp:280
-                        finish(false);
-                        rec.w = 3u; lvl = 0u;
-                    } else {
-                        leaf_i = 0;
-                        if (w1 & 4u) { rec = recs[w1 >> 3]; lvl = 0u; }
-                        else { rec.x = w0; rec.y = w1; lvl = 1u; }
-                    }
-                } else {
-                    finish(false);
-                    rec.w = 3u; lvl = 0u;
-                }
-            }
-        }
-    }
-    if (group_mode) {
-        const unsigned long long m = __ballot(occ);
-        if (group_base != kMiss && lane == 0) P.bits[group_base >> 6] = m;
-    }
-    if (STATS && lane == 0 && P.stats) {
-        atomicAdd(P.stats + 0, (unsigned long long)st_rounds);
-        atomicAdd(P.stats + 1, (unsigned long long)st_t_iters);
-        atomicAdd(P.stats + 2, (unsigned long long)st_t_lanes);
-        atomicAdd(P.stats + 3, (unsigned long long)st_l_rounds);
-        atomicAdd(P.stats + 4, (unsigned long long)st_l_lanes);
-        atomicAdd(P.stats + 5, (unsigned long long)st_refills);
-        atomicAdd(P.stats + 6, (unsigned long long)st_refill_lanes);
-        atomicAdd(P.stats + 7, (unsigned long long)st_rays_lanes);
-        const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
-        atomicMax(P.stats + 8, ~st_t0);
         atomicMax(P.stats + 9, t_end);
         atomicAdd(P.stats + 10, t_end);
         atomicAdd(P.stats + 11, 1ull);
@@ -886,73 +701,99 @@ struct Options {
                               // cost more than the 1.7 ms the regrouped traversal saves
     int sort_bits = 6;        // cells per axis = 2^sort_bits (4..6)
     int treelet_levels = 3;   // read at gigl_scene_create: levels of child pairs per cache-line treelet (1..5)
+    int build_threads = 0;    // read at gigl_scene_create: host threads of the tree build (0: min(16, cores)); the
+                              // tree does not depend on it
     int layout = 2;           // read at gigl_scene_create (kd_layout.h): 0 level treelets + separate id lists,
                               // 1 clustered lines with the id lists in their leaves' lines, 2 triple records
-                              // (two levels per load, trace3_kernel; falls back to 1 beyond its encoding)
+                              // (two levels per load; falls back to 1 beyond its encoding)
 };
 Options g_opt;
 std::mutex g_opt_mu;
 unsigned long long g_last_stats[12] = {0};
 
-template <bool ANY, int GEN, int STACK_N>
-int launch_trace_t(const gigl_scene* s, TraceParams& P, const Options& opt, hipStream_t st) {
-    auto kern = s->triples ? trace3_kernel<ANY, GEN, STACK_N, kBlock> : trace_kernel<ANY, GEN, STACK_N, kBlock>;
+constexpr unsigned kSpillDepth = 32 - 8;          // entries per lane beyond the 8 in LDS (stack of 32, KdTree.hpp:276)
+
+// Workspace handed in by the caller of launch_trace instead of a stream-ordered allocation.
+struct ExtWorkspace {
+    void* base;           // 256 bytes of counters, then the spill area
+    unsigned max_grid;    // workgroups the spill area was sized for (kSpillDepth entries per lane)
+};
+
+template <bool ANY, int GEN, int STACK_N, int BLOCK = kBlock>
+int launch_trace_t(const gigl_scene* s, TraceParams& P, const Options& opt, hipStream_t st, const ExtWorkspace* ext) {
+    auto kern = s->triples ? trace_kernel<true, ANY, GEN, STACK_N, BLOCK> : trace_kernel<false, ANY, GEN, STACK_N, BLOCK>;
     // instrumented builds: explicit-ray closest-hit with the default LDS stack only
-    const bool stats = !ANY && GEN == 0 && STACK_N == 8 && opt.stats;
-    if (stats) kern = s->triples ? trace3_kernel<ANY, GEN, 8, kBlock, true> : trace_kernel<ANY, GEN, 8, kBlock, true>;
-    int per_cu = opt.blocks_per_cu;
-    if (per_cu <= 0) {
-        static int cached[3] = {0, 0, 0};  // per instantiation; [1] is the instrumented build, [2] the triple-layout kernel
-        int& c = cached[stats ? 1 : s->triples ? 2 : 0];
-        if (c <= 0) {
-            int q = 0;
-            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, kern, kBlock, 0));
-            c = q < 1 ? 1 : q;
+    const bool stats = !ANY && GEN == 0 && STACK_N == 8 && BLOCK == kBlock && opt.stats && !ext;
+    if (stats) kern = s->triples ? trace_kernel<true, ANY, GEN, 8, BLOCK, true> : trace_kernel<false, ANY, GEN, 8, BLOCK, true>;
+    unsigned grid;
+    if (ext) {
+        grid = ext->max_grid;
+    } else {
+        int per_cu = opt.blocks_per_cu;
+        if (per_cu <= 0) {
+            // one cache per instantiation (this function is a template), layout and instrumented build;
+            // the devices of a node are identical, so it is not keyed by device
+            static std::atomic<int> cached[4] = {{0}, {0}, {0}, {0}};
+            std::atomic<int>& c = cached[(stats ? 2 : 0) + (s->triples ? 1 : 0)];
+            int q = c.load(std::memory_order_relaxed);
+            if (q <= 0) {
+                HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, kern, BLOCK, 0));
+                q = q < 1 ? 1 : q;
+                c.store(q, std::memory_order_relaxed);
+            }
+            per_cu = q;
         }
-        per_cu = c;
+        grid = (unsigned)(s->n_cus * per_cu);
+        if (getenv("GIGL_RT_DEBUG")) fprintf(stderr, "[gigl_rt] trace launch: %d blocks/CU x %d CUs\n", per_cu, s->n_cus);
     }
-    unsigned grid = (unsigned)(s->n_cus * per_cu);
-    if (getenv("GIGL_RT_DEBUG")) fprintf(stderr, "[gigl_rt] trace launch: %d blocks/CU x %d CUs\n", per_cu, s->n_cus);
-    const unsigned need = (P.n + kBlock - 1) / kBlock;
+    const unsigned need = (P.n + BLOCK - 1) / BLOCK;
     if (grid > need) grid = need;
     if (grid == 0) return GIGL_OK;
     const bool spill = STACK_N < 32 && s->tree.actual_depth - 1 > STACK_N;
-    const size_t spill_entries = spill ? (size_t)grid * kBlock * (size_t)(32 - STACK_N) : 0;
-    const size_t ws_bytes = 256 + spill_entries * sizeof(uint4);
     void* ws = nullptr;
-    HIP_TRY(hipMallocAsync(&ws, ws_bytes, st));
-    if (hipMemsetAsync(ws, 0, 256, st) != hipSuccess) {
-        (void)hipFreeAsync(ws, st);
+    if (ext) {
+        static_assert(STACK_N >= 8, "the external spill area holds 32 - 8 entries per lane");
+        ws = ext->base;
+    } else {
+        const size_t spill_entries = spill ? (size_t)grid * BLOCK * (size_t)(32 - STACK_N) : 0;
+        HIP_TRY(hipMallocAsync(&ws, 256 + spill_entries * sizeof(uint4), st));
+    }
+    if (!P.reset_counter && hipMemsetAsync(ws, 0, 256, st) != hipSuccess) {
+        if (!ext) (void)hipFreeAsync(ws, st);
         return fail(GIGL_ERR_HIP, "hipMemsetAsync(workspace)");
     }
     P.counter = (unsigned*)ws;
     P.spill = (uint4*)((char*)ws + 256);
-    P.spill_stride = grid * kBlock;
+    P.spill_stride = grid * BLOCK;
     // guided requests only for batches that are long against the machine: a small batch would run
     // on minimum-size requests from its first ray (one atomic round trip per refill)
-    P.guided = opt.guided > 0 ? grid * (kBlock / 64u) * (unsigned)opt.guided : 0u;
+    P.guided = opt.guided > 0 ? grid * (BLOCK / 64u) * (unsigned)opt.guided : 0u;
     if ((uint64_t)P.n < 2ull * P.guided * P.chunk) P.guided = 0u;
     P.stats = nullptr;
     if (stats) P.stats = (unsigned long long*)((char*)ws + 128);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, st, P);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), 0, st, P);
     hipError_t le = hipGetLastError();
     if (P.stats && le == hipSuccess) {  // diagnostic path: synchronous read-back
         std::lock_guard<std::mutex> lk(g_opt_mu);
         (void)hipMemcpyAsync(g_last_stats, P.stats, sizeof(g_last_stats), hipMemcpyDeviceToHost, st);
         (void)hipStreamSynchronize(st);
     }
-    hipError_t fe = hipFreeAsync(ws, st);
+    hipError_t fe = ext ? hipSuccess : hipFreeAsync(ws, st);
     if (le != hipSuccess) return fail(GIGL_ERR_HIP, std::string("trace kernel launch: ") + hipGetErrorString(le));
     if (fe != hipSuccess) return fail(GIGL_ERR_HIP, std::string("hipFreeAsync: ") + hipGetErrorString(fe));
     return GIGL_OK;
 }
 
 template <bool ANY, int GEN>
-int launch_trace(const gigl_scene* s, TraceParams& P, hipStream_t st) {
+int launch_trace(const gigl_scene* s, TraceParams& P, hipStream_t st, const ExtWorkspace* ext = nullptr) {
     Options opt;
     {
         std::lock_guard<std::mutex> lk(g_opt_mu);
         opt = g_opt;
+    }
+    if (ext) {   // no allocation of any kind: no regrouping pass, the spill area is sized for 8 LDS entries
+        opt.sort_rays = 0;
+        opt.stack_lds = 8;
     }
     P.nodes = s->d_nodes;
     P.root = s->root;
@@ -1010,14 +851,14 @@ int launch_trace(const gigl_scene* s, TraceParams& P, hipStream_t st) {
     // smallest LDS stack that holds the deepest possible stack avoids the spill path entirely
     int sn = opt.stack_lds;
     const int deepest = s->tree.actual_depth - 1;
-    if (deepest <= 8) sn = 8;
+    if (deepest <= 8 || ext) sn = 8;
     else if (deepest <= 12 && sn >= 12) sn = 12;
     else if (deepest <= 16 && sn >= 16) sn = 16;
     if (rc == GIGL_OK) switch (sn) {
-        case 8: rc = launch_trace_t<ANY, GEN, 8>(s, P, opt, st); break;
-        case 12: rc = launch_trace_t<ANY, GEN, 12>(s, P, opt, st); break;
-        case 16: rc = launch_trace_t<ANY, GEN, 16>(s, P, opt, st); break;
-        case 32: rc = launch_trace_t<ANY, GEN, 32>(s, P, opt, st); break;
+        case 8: rc = launch_trace_t<ANY, GEN, 8>(s, P, opt, st, ext); break;
+        case 12: rc = launch_trace_t<ANY, GEN, 12>(s, P, opt, st, ext); break;
+        case 16: rc = launch_trace_t<ANY, GEN, 16>(s, P, opt, st, ext); break;
+        case 32: rc = launch_trace_t<ANY, GEN, 32>(s, P, opt, st, ext); break;
         default: rc = fail(GIGL_ERR_INVALID, "option stack_lds must be 8, 12, 16 or 32");
     }
     if (sort_ws && hipFreeAsync(sort_ws, st) != hipSuccess && rc == GIGL_OK) rc = fail(GIGL_ERR_HIP, "hipFreeAsync");
@@ -1110,6 +951,9 @@ int gigl_set_option(const char* name, int value) {
     } else if (k == "guided") {
         if (value < 0 || value > 64) return fail(GIGL_ERR_INVALID, "guided must be in 0..64");
         g_opt.guided = value;
+    } else if (k == "build_threads") {
+        if (value < 0 || value > 256) return fail(GIGL_ERR_INVALID, "build_threads must be in 0..256");
+        g_opt.build_threads = value;
     } else if (k == "blocks_per_cu") {
         if (value < 0 || value > 8) return fail(GIGL_ERR_INVALID, "blocks_per_cu must be in 0..8");
         g_opt.blocks_per_cu = value;
@@ -1133,11 +977,12 @@ int gigl_scene_create(const float* verts, uint32_t n_verts, const uint32_t* tris
         if (device < 0 || device >= n_dev) return fail(GIGL_ERR_INVALID, "device index out of range");
     }
 
-    int treelet_levels, layout;
+    int treelet_levels, layout, build_threads;
     {
         std::lock_guard<std::mutex> lk(g_opt_mu);
         treelet_levels = g_opt.treelet_levels;
         layout = g_opt.layout;
+        build_threads = g_opt.build_threads;
     }
     gigl_scene* s = new gigl_scene();
     s->device = device;
@@ -1145,6 +990,7 @@ int gigl_scene_create(const float* verts, uint32_t n_verts, const uint32_t* tris
     gigl::KdBuildParams bp;
     bp.inters_cost = inters_cost; bp.trav_cost = trav_cost; bp.max_depth = max_depth;
     bp.min_num_prims = min_num_prims; bp.empty_bonus = empty_bonus;
+    bp.n_threads = build_threads;
     const char* err = nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     if (!gigl::kd_build(verts, n_verts, tris, n_tris, bp, s->tree, &err)) {
@@ -1200,6 +1046,7 @@ int gigl_scene_create(const float* verts, uint32_t n_verts, const uint32_t* tris
     if (layout == 1) { dtree = gigl::DeviceTree(); gigl::layout_clustered(s->tree, dtree); }
     else if (layout == 0) gigl::layout_levels(s->tree, treelet_levels, dtree);
     s->triples = dtree.triples;
+    s->layout = layout;
     const std::vector<gigl::KdNode>& dn = dtree.slots;
     const bool ids_inline = dtree.ids_inline;
     // device node word 1 keeps 29 bits for a triangle id / leaf size and 29 for a node slot
@@ -1214,7 +1061,9 @@ int gigl_scene_create(const float* verts, uint32_t n_verts, const uint32_t* tris
         if (s->d_nodes) (void)hipFree(s->d_nodes);
         if (s->d_leaf_ids) (void)hipFree(s->d_leaf_ids);
         if (s->d_tris) (void)hipFree(s->d_tris);
-        if (s->d_one) (void)hipFree(s->d_one);
+        if (s->h_one) (void)hipHostFree(s->h_one);
+        if (s->one_ws) (void)hipFree(s->one_ws);
+        if (s->one_stream) (void)hipStreamDestroy(s->one_stream);
         delete s;
     };
 #define CREATE_TRY(expr)                                                                      \
@@ -1228,7 +1077,12 @@ int gigl_scene_create(const float* verts, uint32_t n_verts, const uint32_t* tris
     CREATE_TRY(hipMalloc((void**)&s->d_nodes, nb_nodes));
     if (!ids_inline) CREATE_TRY(hipMalloc((void**)&s->d_leaf_ids, nb_leaf));
     CREATE_TRY(hipMalloc((void**)&s->d_tris, nb_tris));
-    CREATE_TRY(hipMalloc((void**)&s->d_one, 64));
+    CREATE_TRY(hipHostMalloc((void**)&s->h_one, 7 * sizeof(float4), hipHostMallocMapped));
+    CREATE_TRY(hipHostGetDevicePointer((void**)&s->d_one, s->h_one, 0));
+    const size_t one_ws_bytes = 256 + (size_t)64 * kSpillDepth * sizeof(uint4);
+    CREATE_TRY(hipMalloc(&s->one_ws, one_ws_bytes));
+    CREATE_TRY(hipMemset(s->one_ws, 0, 256));
+    CREATE_TRY(hipStreamCreateWithFlags(&s->one_stream, hipStreamNonBlocking));
     CREATE_TRY(hipMemcpy(s->d_nodes, dn.data(), dn.size() * 8, hipMemcpyHostToDevice));
     if (!ids_inline && !dtree.ids.empty())
         CREATE_TRY(hipMemcpy(s->d_leaf_ids, dtree.ids.data(), dtree.ids.size() * 4, hipMemcpyHostToDevice));
@@ -1251,7 +1105,9 @@ int gigl_scene_destroy(gigl_scene* s) {
     (void)hipFree(s->d_nodes);
     (void)hipFree(s->d_leaf_ids);
     (void)hipFree(s->d_tris);
-    (void)hipFree(s->d_one);
+    (void)hipHostFree(s->h_one);
+    (void)hipFree(s->one_ws);
+    if (s->one_stream) (void)hipStreamDestroy(s->one_stream);
     delete s;
     return GIGL_OK;
 }
@@ -1345,40 +1201,62 @@ int gigl_trace_any(const gigl_scene* s, const float* o_tmin, const float* d_tmax
     return trace_host(s, o_tmin, d_tmax, n, occluded_bits, (n + 63) / 64 * 8, true);
 }
 
+int gigl_scene_layout(const gigl_scene* s, int* layout_out) {
+    if (!s || !layout_out) return fail(GIGL_ERR_INVALID, "NULL argument");
+    *layout_out = s->layout;
+    return GIGL_OK;
+}
+
 int gigl_trace_one(const gigl_scene* s, const float o[3], const float d[3], float t_min, float t_max,
                    int is_vis_ray, int* hit_out, gigl_hit* hit_rec, float normal_out[3], float range_out[2]) {
     if (!s || !o || !d || !hit_out) return fail(GIGL_ERR_INVALID, "NULL argument");
     if (s->device == GIGL_DEVICE_NONE) return fail(GIGL_ERR_NO_DEVICE, "host-only scene: no device to trace on");
     // Scene::trace semantics on one ray: a closest-hit launch answers both modes (the bool of a
-    // visibility ray equals the bool of the closest-hit query; only the early-out differs).
-    const float ro[4] = {o[0], o[1], o[2], t_min}, rd[4] = {d[0], d[1], d[2], t_max};
-    gigl_hit h;
-    std::lock_guard<std::mutex> lk(const_cast<gigl_scene*>(s)->one_mu);
+    // visibility ray equals the bool of the closest-hit query; only the early-out differs, so for a
+    // visibility ray the record and the normal are those of the CLOSEST hit, where KdTree.hpp:328
+    // would leave those of the first hit found — no reference caller passes true and reads them).
+    // One single-wave launch reads the ray from pinned host memory and writes the record, the range
+    // and the hit triangle's record back to it: no copy, no allocation, one synchronisation.
+    gigl_scene* ms = const_cast<gigl_scene*>(s);
+    std::lock_guard<std::mutex> lk(ms->one_mu);
     DeviceGuard g(s->device);
-    HIP_TRY(hipMemcpy(s->d_one, ro, 16, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(s->d_one + 1, rd, 16, hipMemcpyHostToDevice));
+    float* h = reinterpret_cast<float*>(s->h_one);
+    h[0] = o[0]; h[1] = o[1]; h[2] = o[2]; h[3] = t_min;
+    h[4] = d[0]; h[5] = d[1]; h[6] = d[2]; h[7] = t_max;
     TraceParams P = {};
     P.n = 1;
     P.o_tmin = s->d_one;
     P.d_tmax = s->d_one + 1;
     P.hits = (uint4*)(s->d_one + 2);
     P.ranges = (float2*)(s->d_one + 3);
-    int rc = launch_trace<false, 0>(s, P, nullptr);
+    P.hit_tri = s->d_one + 4;
+    P.reset_counter = 1u;
+    Options opt;
+    {
+        std::lock_guard<std::mutex> lk2(g_opt_mu);
+        opt = g_opt;
+    }
+    P.nodes = s->d_nodes; P.root = s->root;
+    P.recs = reinterpret_cast<const uint4*>(s->d_nodes); P.root_rec = s->root_rec;
+    P.leaf_ids = s->d_leaf_ids ? s->d_leaf_ids : reinterpret_cast<const unsigned*>(s->d_nodes);
+    P.tris = s->d_tris;
+    P.box = s->box;
+    P.refill_thresh = 1; P.chunk = 64; P.t_exit = 1;
+    opt.guided = 0; opt.stats = 0;
+    const ExtWorkspace ext = {s->one_ws, 1u};
+    int rc = launch_trace_t<false, 0, 8, 64>(s, P, opt, s->one_stream, &ext);
     if (rc != GIGL_OK) return rc;
-    float back[8];
-    HIP_TRY(hipMemcpy(back, s->d_one + 2, 32, hipMemcpyDeviceToHost));
-    memcpy(&h, back, 16);
-    if (range_out) { range_out[0] = back[4]; range_out[1] = back[5]; }
-    *hit_out = h.tri_id != GIGL_MISS;
-    if (hit_rec) *hit_rec = h;
+    HIP_TRY(hipStreamSynchronize(s->one_stream));
+    gigl_hit hrec;
+    memcpy(&hrec, h + 8, 16);
+    if (range_out) { range_out[0] = h[12]; range_out[1] = h[13]; }
+    *hit_out = hrec.tri_id != GIGL_MISS;
+    if (hit_rec) *hit_rec = hrec;
     if (normal_out) {
         normal_out[0] = normal_out[1] = normal_out[2] = 0.0f;
         if (*hit_out) {
             // cross(edge0, edge1) (RTBase.cpp:170); normalized for non-visibility rays (Scene.cpp:238)
-            const gigl::KdTreeHost& T = s->tree;
-            (void)T;
-            float rec[12];
-            HIP_TRY(hipMemcpy(rec, s->d_tris + kTriStride * (size_t)h.tri_id, 48, hipMemcpyDeviceToHost));
+            const float* rec = h + 16;
             const float e0x = rec[3], e0y = rec[4], e0z = rec[5], e1x = rec[6], e1y = rec[7], e1z = rec[8];
             float nx = e0y * e1z - e1y * e0z, ny = e0z * e1x - e1z * e0x, nz = e0x * e1y - e1x * e0y;
             if (!is_vis_ray) {

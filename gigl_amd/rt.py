@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("GIGL_RT_LIB") or os.path.join(_HERE, "lib", "libgigl_
 _LIB = None
 
 GIGL_MISS = 0xFFFFFFFF
+GIGL_DEVICE_NONE = -1
 HIT_DTYPE = np.dtype([("tri_id", "<u4"), ("t", "<f4"), ("u", "<f4"), ("v", "<f4")])
 
 # every symbol include/gigl_rt.h declares
@@ -26,7 +27,7 @@ SYMBOLS = [
     "gigl_fog_destroy", "gigl_transmittance_device", "gigl_sample_density", "gigl_debug_rescaled_eps",
     "gigl_set_option", "gigl_debug_last_stats", "gigl_compute_pi_density_device", "gigl_shade_surface_device",
     "gigl_tonemap_device", "gigl_volume_samples_device", "gigl_shadow_points_device", "gigl_shade_volume_device",
-    "gigl_depth_buffer_device", "gigl_combine_device", "gigl_debug_check_layout",
+    "gigl_depth_buffer_device", "gigl_combine_device", "gigl_debug_check_layout", "gigl_scene_layout",
 ]
 
 
@@ -77,6 +78,7 @@ def lib():
         L.gigl_scene_export_tree.argtypes = [vp, vp, vp]
         L.gigl_trace_closest_device.argtypes = [vp, vp, vp, u64, vp, vp]
         L.gigl_trace_closest.argtypes = [vp, vp, vp, u64, vp]
+        L.gigl_scene_layout.argtypes = [vp, vp]
         L.gigl_trace_any_device.argtypes = [vp, vp, vp, u64, vp, vp]
         L.gigl_trace_any.argtypes = [vp, vp, vp, u64, vp]
         L.gigl_trace_one.argtypes = [vp, vp, vp, f, f, i, vp, vp, vp, vp]
@@ -221,6 +223,12 @@ class Scene:
         st = TreeStats()
         _check(lib().gigl_scene_stats(self.h, C.byref(st)))
         return st
+
+    def layout(self):
+        """The device layout in use: 0 level treelets, 1 clustered lines, 2 triple records."""
+        v = C.c_int(-1)
+        _check(lib().gigl_scene_layout(self.h, C.byref(v)))
+        return v.value
 
     def check_layout(self, layout=1, treelet_levels=3):
         """Rebuilds the device layout on the host and checks it against the tree; returns its bytes."""

@@ -89,6 +89,10 @@ int gigl_scene_destroy(gigl_scene* s);
 /* KdTree::bbox (Source/RT/KdTree.h:18): out = min xyz, max xyz. */
 int gigl_scene_bbox(const gigl_scene* s, float out[6]);
 int gigl_scene_stats(const gigl_scene* s, gigl_tree_stats* out);
+/* The device layout the scene's kernels walk (DESIGN.md "Data layout"): 0 level treelets, 1 clustered
+ * lines, 2 triple records.  Option "layout" = 2 falls back to 1 when a tree exceeds the record
+ * encoding, so this is how a caller (bench.py) names the kernel variant that actually ran. */
+int gigl_scene_layout(const gigl_scene* s, int* layout_out);
 /* The host tree in the reference's 8-byte node encoding (Source/RT/KdTree.h:22-65), for tree
  * digests: nodes_words uint32[2*n_nodes], leaf_prim_ids uint32[n_leaf_prim_ids]. */
 int gigl_scene_export_tree(const gigl_scene* s, uint32_t* nodes_words, uint32_t* leaf_prim_ids);

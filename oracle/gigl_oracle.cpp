@@ -560,6 +560,55 @@ ora_scene* ora_scene_create(const float* verts, uint32_t n_verts, const uint32_t
     return S;
 }
 
+/* A scene over a tree that was built elsewhere (the engine's exported tree, in the reference's node
+ * encoding): for scenes whose serial build here would take minutes (10 M triangles), SURVEY.md §7
+ * allows "the build's own tree as ground truth for large scenes".  Traversal (KdTree.hpp:266-347) and
+ * every caller of it work on it as on a scene built by ora_scene_create; the tree box is the union
+ * of the triangles' boxes, as the constructor computes it (KdTree.hpp:100-106). */
+ora_scene* ora_scene_from_tree(const float* verts, uint32_t n_verts, const uint32_t* tris, uint32_t n_tris,
+                               const uint32_t* nodes_words, uint32_t n_nodes, const uint32_t* leaf_prim_ids,
+                               uint32_t n_leaf_prim_ids) {
+    ora_scene* S = new ora_scene();
+    S->verts.resize(n_verts);
+    for (uint32_t i = 0; i < n_verts; ++i) S->verts[i] = v3(verts[3 * i], verts[3 * i + 1], verts[3 * i + 2]);
+    S->tris.assign(tris, tris + 4 * (size_t)n_tris);
+    S->n_tris = n_tris;
+    S->max_depth = S->actual_depth = 0; S->min_num_prims = 1; S->inters_cost = S->trav_cost = 0;
+    S->empty_bonus = 0.0f; S->avg_prims_per_leaf = 0.0f; S->leaf_count = 0;
+    for (uint32_t i = 0; i < n_tris; ++i) {
+        Box b;                                                        /* Triangle::computeBBox, RTBase.cpp:142-148 */
+        for (int k = 0; k < 3; ++k) b.extend(S->verts[S->tris[4 * (size_t)i + k]]);
+        S->tree_box.extend(b);
+    }
+    S->nodes.resize(n_nodes);
+    memcpy(S->nodes.data(), nodes_words, (size_t)n_nodes * 8);
+    S->leaf_prim_ids.assign(leaf_prim_ids, leaf_prim_ids + n_leaf_prim_ids);
+    S->next_node_id = n_nodes;
+    double prims = 0.0;
+    for (uint32_t i = 0; i < n_nodes; ++i)
+        if (n_is_leaf(S->nodes[i])) { ++S->leaf_count; prims += n_nprims(S->nodes[i]); }
+    if (S->leaf_count) S->avg_prims_per_leaf = (float)(prims / S->leaf_count);
+    return S;
+}
+
+/* Scene::trace on ONE ray, with everything the caller's Ray holds afterwards: the bool, the hit
+ * record, the normal as Scene::trace leaves it (normalized for closest-hit rays, cross(e0,e1) for
+ * visibility rays; Scene.cpp:234-243) and the ray's (t_min, t_max) as KdTree::intersect leaves
+ * them (KdTree.hpp:273-274, :310, :337-338). */
+int ora_trace_one(const ora_scene* s, const float o[3], const float d[3], float t_min, float t_max, int is_vis_ray,
+                  void* hit16, float normal_out[3], float range_out[2]) {
+    Ray r = make_ray(v3(o[0], o[1], o[2]), v3(d[0], d[1], d[2]));
+    r.t_min = t_min; r.t_max = t_max;
+    const bool hit = scene_trace(*s, r, is_vis_ray != 0);
+    Hit16 h;
+    if (hit) { h.tri_id = r.tri_id; h.t = r.dist; h.u = r.u; h.v = r.v; }
+    else { h.tri_id = 0xFFFFFFFFu; h.t = FLT_MAX; h.u = 0.0f; h.v = 0.0f; }
+    if (hit16) memcpy(hit16, &h, 16);
+    if (normal_out) { normal_out[0] = r.normal.x; normal_out[1] = r.normal.y; normal_out[2] = r.normal.z; }
+    if (range_out) { range_out[0] = r.t_min; range_out[1] = r.t_max; }
+    return hit ? 1 : 0;
+}
+
 void ora_scene_destroy(ora_scene* s) { delete s; }
 uint32_t ora_scene_n_nodes(const ora_scene* s) { return (uint32_t)s->nodes.size(); }
 uint32_t ora_scene_n_leaf_prim_ids(const ora_scene* s) { return (uint32_t)s->leaf_prim_ids.size(); }

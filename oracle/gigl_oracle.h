@@ -31,6 +31,12 @@ typedef struct ora_scene ora_scene;
 ora_scene* ora_scene_create(const float* verts, uint32_t n_verts, const uint32_t* tris,
                             uint32_t n_tris, int inters_cost, int trav_cost, int max_depth,
                             uint32_t min_num_prims, float empty_bonus);
+/* A scene over a tree built elsewhere, given in the reference's node encoding (below): used for
+ * scenes too large to build serially here ("the build's own tree as ground truth for
+ * large scenes").  Tree box = union of the triangles' boxes (KdTree.hpp:100-106). */
+ora_scene* ora_scene_from_tree(const float* verts, uint32_t n_verts, const uint32_t* tris, uint32_t n_tris,
+                               const uint32_t* nodes_words, uint32_t n_nodes, const uint32_t* leaf_prim_ids,
+                               uint32_t n_leaf_prim_ids);
 void ora_scene_destroy(ora_scene* s);
 
 /* Statistics the reference prints (Source/RT/KdTree.hpp:126-131). */
@@ -65,6 +71,12 @@ void ora_trace_closest(const ora_scene* s, const float* rays_o_tmin, const float
 /* is_vis_ray = true (Source/RT/KdTree.hpp:267,328).  occluded: uint8[n] (0/1). */
 void ora_trace_any(const ora_scene* s, const float* rays_o_tmin, const float* rays_d_tmax,
                    uint64_t n, uint8_t* occluded, uint32_t* counters, int n_threads);
+
+/* Scene::trace on one ray: returns the bool; hit16 = record (or a miss record), normal_out = the
+ * normal as Scene::trace leaves it (Scene.cpp:238: normalized only for closest-hit rays), range_out =
+ * the ray's (t_min, t_max) as KdTree::intersect leaves them (KdTree.hpp:273-274, :310, :337-338). */
+int ora_trace_one(const ora_scene* s, const float o[3], const float d[3], float t_min, float t_max,
+                  int is_vis_ray, void* hit16, float normal_out[3], float range_out[2]);
 
 /* PerspectiveCamera ctor + getPrimaryRay (Source/Common/Camera.cpp:15-33, :65-68).
  * cam_out: float[12] = pos, bottom_left, step_x, step_y. */

@@ -35,6 +35,12 @@ def lib():
         L.ora_scene_create.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, C.c_int,
                                        C.c_int, C.c_uint32, C.c_float]
         L.ora_scene_destroy.argtypes = [C.c_void_p]
+        L.ora_scene_from_tree.restype = C.c_void_p
+        L.ora_scene_from_tree.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
+                                          C.c_void_p, C.c_uint32]
+        L.ora_trace_one.restype = C.c_int
+        L.ora_trace_one.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_void_p,
+                                    C.c_void_p, C.c_void_p]
         for f in ("ora_scene_n_nodes", "ora_scene_n_leaf_prim_ids", "ora_scene_leaf_count"):
             getattr(L, f).restype = C.c_uint32
             getattr(L, f).argtypes = [C.c_void_p]
@@ -117,9 +123,17 @@ class Fog:
 
 class OracleScene:
     def __init__(self, verts, tris, inters_cost=10, trav_cost=1, max_depth=30, min_num_prims=2,
-                 empty_bonus=0.25):
+                 empty_bonus=0.25, tree=None):
+        """tree = (nodes uint32[n,2], leaf_prim_ids uint32[m]) in the reference's encoding: traverse that
+        tree instead of building one (large scenes; see ora_scene_from_tree)."""
         self.verts = _f32(verts).reshape(-1, 3)
         self.tris = np.ascontiguousarray(tris, dtype=np.uint32).reshape(-1, 4)
+        if tree is not None:
+            nodes = np.ascontiguousarray(tree[0], dtype=np.uint32).reshape(-1, 2)
+            leaf = np.ascontiguousarray(tree[1], dtype=np.uint32).reshape(-1)
+            self.h = lib().ora_scene_from_tree(_p(self.verts), len(self.verts), _p(self.tris), len(self.tris),
+                                               _p(nodes), len(nodes), _p(leaf), len(leaf))
+            return
         self.h = lib().ora_scene_create(_p(self.verts), len(self.verts), _p(self.tris), len(self.tris),
                                         inters_cost, trav_cost, max_depth, min_num_prims, empty_bonus)
 
@@ -172,6 +186,15 @@ class OracleScene:
         cnt = np.zeros((n, 2), np.uint32) if counters else None
         lib().ora_trace_closest(self.h, _p(ro), _p(rd), n, _p(hits), _p(cnt), n_threads)
         return (hits, cnt) if counters else hits
+
+    def trace_one(self, o, d, t_min=0.0, t_max=float(np.finfo(np.float32).max), is_vis_ray=False):
+        """Scene::trace on one ray: (hit, record, normal, (t_min, t_max) left in the ray)."""
+        rec = np.zeros(1, HIT_DTYPE)
+        nrm = np.zeros(3, np.float32)
+        rng = np.zeros(2, np.float32)
+        hit = lib().ora_trace_one(self.h, _p(_f32(o)), _p(_f32(d)), t_min, t_max, int(is_vis_ray), _p(rec), _p(nrm),
+                                  _p(rng))
+        return bool(hit), rec[0], nrm, rng
 
     def trace_any(self, ro, rd, counters=False, n_threads=1):
         ro, rd = _f32(ro).reshape(-1, 4), _f32(rd).reshape(-1, 4)

@@ -249,14 +249,80 @@ def test_shared_edge_and_vertex_ties(gpu_cornell, oracle_cornell, cornell):
     assert_hits_equal(gpu_cornell.trace(ro, rd), oracle_cornell.trace_closest(ro, rd))
 
 
-def test_trace_one(gpu_cornell, oracle_cornell):
-    hit, rec, nrm = gpu_cornell.trace_one([278, 273, -800], [0, 0, 1])
-    want = oracle_cornell.trace_closest(np.array([[278, 273, -800, 0]], np.float32),
-                                        np.array([[0, 0, 1, FLT_MAX]], np.float32))[0]
-    assert hit and rec["tri_id"] == want["tri_id"] and rec["t"] == want["t"]
-    assert abs(float(np.linalg.norm(nrm)) - 1.0) < 1e-6
-    hit, rec, _ = gpu_cornell.trace_one([278, 273, -800], [0, 0, -1])
-    assert not hit and rec["tri_id"] == rt.GIGL_MISS
+def _cross_f32(e0, e1):
+    """cross(e0, e1) in GLM's operation order (func_geometric.inl:224-227), float32."""
+    f = np.float32
+    return np.array([f(e0[1] * e1[2]) - f(e1[1] * e0[2]), f(e0[2] * e1[0]) - f(e1[2] * e0[0]),
+                     f(e0[0] * e1[1]) - f(e1[0] * e0[1])], np.float32)
+
+
+def test_trace_one(gpu_cornell, oracle_cornell, cornell, cornell_cam):
+    """gigl_trace_one against Scene::trace on one ray (oracle): the bool, the record, the normal as
+    Scene::trace leaves it (normalized for closest-hit rays, cross(e0,e1) for visibility rays) and the
+    (t_min, t_max) KdTree::intersect leaves in the caller's ray, bit for bit."""
+    V, T = cornell["verts"], cornell["tris"]
+    po, pd = O.primary_rays(cornell_cam, 1024, 0, 1024 * 1024)
+    rays = [(po[i, :3], pd[i, :3], 0.0, FLT_MAX) for i in range(0, 1024 * 1024, 9973)]
+    rays += [([278, 273, -800], [0, 0, 1], 0.0, FLT_MAX), ([278, 273, -800], [0, 0, -1], 0.0, FLT_MAX),
+             ([278, 273, -800], [0, 0, 1], 0.0, 100.0), ([278, 273, -800], [0, 0, 1], 2000.0, FLT_MAX),
+             ([278, 273, 100], [0, 1, 0], 0.0, FLT_MAX), ([278, 273, 100], [0.6, 0.0, 0.8], 0.0, 50.0),
+             ([0, 273, -800], [0, 0, 1], 0.0, FLT_MAX), ([278, 273, 100], [np.nan, 0, 1], 0.0, FLT_MAX)]
+    n_hit = 0
+    for o, d, t0, t1 in rays:
+        hit, rec, nrm = gpu_cornell.trace_one(o, d, t0, t1)
+        rng = gpu_cornell.last_range.copy()
+        w_hit, w_rec, w_nrm, w_rng = oracle_cornell.trace_one(o, d, t0, t1)
+        assert hit == w_hit and rec["tri_id"] == w_rec["tri_id"]
+        for k in ("t", "u", "v"):
+            assert rec[k].view(np.uint32) == w_rec[k].view(np.uint32), k
+        assert np.array_equal(rng.view(np.uint32), w_rng.view(np.uint32)), "range_out"
+        if hit:
+            n_hit += 1
+            assert np.array_equal(nrm.view(np.uint32), w_nrm.view(np.uint32)), "normal_out"
+            assert abs(float(np.linalg.norm(nrm)) - 1.0) < 1e-6
+        # visibility ray: the bool is the reference's; the record is the closest hit's (documented in
+        # include/gigl_rt.h), so the normal is checked as cross(e0, e1) of the triangle it names
+        v_hit, v_rec, v_nrm = gpu_cornell.trace_one(o, d, t0, t1, is_vis_ray=True)
+        w_vhit, w_vrec, w_vnrm, _ = oracle_cornell.trace_one(o, d, t0, t1, is_vis_ray=True)
+        assert v_hit == w_vhit == hit
+        if v_hit:
+            t = T[v_rec["tri_id"]]
+            want_n = _cross_f32(V[t[1]] - V[t[0]], V[t[2]] - V[t[0]])
+            assert np.array_equal(v_nrm.view(np.uint32), want_n.view(np.uint32))
+            if v_rec["tri_id"] == w_vrec["tri_id"]:
+                assert np.array_equal(v_nrm.view(np.uint32), w_vnrm.view(np.uint32))
+    assert n_hit > 50
+
+
+def test_concurrent_trace_calls_on_one_scene(s16):
+    """include/gigl_rt.h: trace calls may be issued concurrently on one handle (KdTree::intersect is
+    const and re-entrant, DensityField.cpp:280-293).  Two host threads trace different batches through
+    the same scene at the same time; each gets what it gets alone."""
+    import threading
+    batches = [synth.bounce_rays(s16["V"], s16["T"], 60_001 + 1000 * k, 0x7EAD00 + k) for k in range(2)]
+    alone = [s16["gpu"].trace(ro, rd) for ro, rd in batches]
+    alone_any = [s16["gpu"].trace(ro, rd, is_vis_ray=True) for ro, rd in batches]
+    errors = []
+
+    def worker(k):
+        try:
+            ro, rd = batches[k]
+            for it in range(12):
+                if it % 3 == 2:
+                    assert np.array_equal(s16["gpu"].trace(ro, rd, is_vis_ray=True), alone_any[k])
+                else:
+                    assert np.array_equal(s16["gpu"].trace(ro, rd).view(np.uint32), alone[k].view(np.uint32))
+                hit, rec, _ = s16["gpu"].trace_one(ro[it, :3], rd[it, :3])
+                assert rec["tri_id"] == alone[k]["tri_id"][it]
+        except Exception as e:   # noqa: BLE001 - reported below, in the main thread
+            errors.append((k, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
 
 
 def test_sample_density_and_transmittance(density, fog_box):
@@ -394,4 +460,53 @@ def test_full_size_scene_s158(cornell):
         assert torch.equal(hits, hits2)
     finally:
         rt.set_option("sort_rays", 0)
+    g.close()
+
+
+def test_full_size_scene_s500(cornell):
+    """configs[3]'s scene at full size: S(500) = 10,000,000 triangles, tree depth 31.  The builder's tree
+    does not depend on its thread count (1-thread build on a host-only scene == the device scene's tree);
+    the oracle TRAVERSES THE ENGINE'S EXPORTED TREE ("the build's own tree as ground truth
+    for large scenes" - the serial oracle build of 10 M triangles takes minutes) on the first 2^20 rays
+    of the RAY_SEED_128M batch: ids, t/u/v and any-hit bits bit-exact.  On a 2^24-ray slice of the same
+    batch, the size-independent properties: any-hit bits == (closest-hit id != miss), every hit inside
+    its ray's range."""
+    torch = pytest.importorskip("torch")
+    V, T = synth.tessellate(cornell["verts"], cornell["tris"], 500)
+    assert len(T) == 10_000_000
+    g = rt.Scene(V, T, device=0, **S.KD_PARAMS)
+    st = g.stats()
+    assert st.actual_depth == 31 and st.degenerate_split_guard_hit == 0
+    nodes, leaf = g.export_tree()
+    # thread-count independence: the same tree from a build held to 5 threads (default: min(16, cores))
+    rt.set_option("build_threads", 5)
+    try:
+        h = rt.Scene(V, T, device=rt.GIGL_DEVICE_NONE, **S.KD_PARAMS)
+    finally:
+        rt.set_option("build_threads", 0)
+    n2, l2 = h.export_tree()
+    assert np.array_equal(nodes, n2) and np.array_equal(leaf, l2)
+    h.close()
+    del n2, l2
+    o = O.OracleScene(V, T, tree=(nodes, leaf))
+    assert np.array_equal(o.bbox(), g.bbox())
+    n = 1 << 24
+    ro, rd = synth.bounce_rays(V, T, n, synth.RAY_SEED_128M)
+    d_o, d_d = torch.from_numpy(ro).cuda(), torch.from_numpy(rd).cuda()
+    hits = torch.empty((n, 4), dtype=torch.int32, device="cuda:0")
+    bits = torch.zeros((n + 63) // 64, dtype=torch.int64, device="cuda:0")
+    sh = torch.cuda.current_stream().cuda_stream
+    g.trace_closest_device(d_o.data_ptr(), d_d.data_ptr(), n, hits.data_ptr(), sh)
+    g.trace_any_device(d_o.data_ptr(), d_d.data_ptr(), n, bits.data_ptr(), sh)
+    torch.cuda.synchronize()
+    got = hits.cpu().numpy().view(rt.HIT_DTYPE).reshape(-1)
+    occ = rt.unpack_bits(bits.cpu().numpy().view(np.uint64), n)
+    m = 1 << 20
+    assert_hits_equal(got[:m], o.trace_closest(ro[:m], rd[:m], n_threads=16))
+    assert np.array_equal(occ[:m], o.trace_any(ro[:m], rd[:m], n_threads=16))
+    hit = got["tri_id"] != rt.GIGL_MISS
+    assert np.array_equal(occ.astype(bool), hit)
+    assert 0.5 < hit.mean() <= 1.0
+    assert (got["tri_id"][hit] < len(T)).all() and (got["t"][hit] > 0).all() and np.isfinite(got["t"][hit]).all()
+    assert (got["t"][~hit] == FLT_MAX).all()
     g.close()
