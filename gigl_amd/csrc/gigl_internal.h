@@ -274,6 +274,7 @@ struct gigl_scene {
     gd::BoxF box;
     gigl_tree_stats stats;
     int layout = 2;                // device layout in use (kd_layout.h): 0, 1 or 2 (2 may fall back to 1 at create)
+    void* scratch = nullptr;       // this device's copy of the no-allocation entry point's static scratch array
     // gigl_trace_one: pinned, device-mapped staging (7 float4: ray in, hit record, range and hit
     // triangle out), a persistent workspace for its single-wave launch and a stream of its own, so a
     // call is one memcpy-free launch and one stream synchronisation

@@ -711,7 +711,34 @@ Options g_opt;
 std::mutex g_opt_mu;
 unsigned long long g_last_stats[12] = {0};
 
+// ---- the no-allocation entry point's scratch (gigl_trace_closest_noalloc_device) ----------------
+// A file-scope device array: every GPU the library runs on holds its own copy, at its own address,
+// until the process ends.  Host code never uses the array's name as an address: gigl_scene_create
+// asks hipGetSymbolAddress for it once per device (scratch_for_device) and the pointer it returns
+// is what the kernels, and hipMemsetAsync, are given.
+constexpr unsigned kNoAllocBlocks = 256;          // workgroups of a no-allocation launch (one per CU)
 constexpr unsigned kSpillDepth = 32 - 8;          // entries per lane beyond the 8 in LDS (stack of 32, KdTree.hpp:276)
+constexpr size_t kScratchBytes = 256 + (size_t)kNoAllocBlocks * kBlock * kSpillDepth * sizeof(uint4);   // 24 MiB + 256 B
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mu;
+void* g_scratch_ptr[kMaxDevices] = {nullptr};
+
+// Call with `device` current.  Returns the device address of this GPU's copy of `scratch`.
+int scratch_for_device(int device, void** out) {
+    *out = nullptr;
+    if (device < 0 || device >= kMaxDevices) return fail(GIGL_ERR_INVALID, "device index beyond the scratch table");
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch_ptr[device]) {
+        void* ptr = nullptr;
+        hipError_t e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !ptr) return fail(GIGL_ERR_HIP, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
+        g_scratch_ptr[device] = ptr;
+    }
+    *out = g_scratch_ptr[device];
+    return GIGL_OK;
+}
 
 // Workspace handed in by the caller of launch_trace instead of a stream-ordered allocation.
 struct ExtWorkspace {
@@ -1083,6 +1110,7 @@ int gigl_scene_create(const float* verts, uint32_t n_verts, const uint32_t* tris
     CREATE_TRY(hipMalloc(&s->one_ws, one_ws_bytes));
     CREATE_TRY(hipMemset(s->one_ws, 0, 256));
     CREATE_TRY(hipStreamCreateWithFlags(&s->one_stream, hipStreamNonBlocking));
+    if (scratch_for_device(device, &s->scratch) != GIGL_OK) { cleanup(); return GIGL_ERR_HIP; }
     CREATE_TRY(hipMemcpy(s->d_nodes, dn.data(), dn.size() * 8, hipMemcpyHostToDevice));
     if (!ids_inline && !dtree.ids.empty())
         CREATE_TRY(hipMemcpy(s->d_leaf_ids, dtree.ids.data(), dtree.ids.size() * 4, hipMemcpyHostToDevice));
@@ -1199,6 +1227,22 @@ int gigl_trace_closest(const gigl_scene* s, const float* o_tmin, const float* d_
 int gigl_trace_any(const gigl_scene* s, const float* o_tmin, const float* d_tmax, uint64_t n,
                    uint64_t* occluded_bits) {
     return trace_host(s, o_tmin, d_tmax, n, occluded_bits, (n + 63) / 64 * 8, true);
+}
+
+int gigl_trace_closest_noalloc_device(const gigl_scene* s, const void* o_tmin, const void* d_tmax, uint64_t n,
+                                      gigl_hit* hits, void* stream) {
+    int rc = check_batch(s, o_tmin, d_tmax, n, hits);
+    if (rc != GIGL_OK || n == 0) return rc;
+    if (n > GIGL_NOALLOC_MAX_RAYS) return fail(GIGL_ERR_TOO_LARGE, "gigl_trace_closest_noalloc_device: at most 2^24 rays per call");
+    if (!s->scratch) return fail(GIGL_ERR_HIP, "no scratch array on this device");
+    DeviceGuard g(s->device);
+    TraceParams P = {};
+    P.n = (unsigned)n;
+    P.o_tmin = (const float4*)o_tmin;
+    P.d_tmax = (const float4*)d_tmax;
+    P.hits = (uint4*)hits;
+    const ExtWorkspace ext = {s->scratch, kNoAllocBlocks};
+    return launch_trace<false, 0>(s, P, (hipStream_t)stream, &ext);
 }
 
 int gigl_scene_layout(const gigl_scene* s, int* layout_out) {

@@ -28,6 +28,7 @@ SYMBOLS = [
     "gigl_set_option", "gigl_debug_last_stats", "gigl_compute_pi_density_device", "gigl_shade_surface_device",
     "gigl_tonemap_device", "gigl_volume_samples_device", "gigl_shadow_points_device", "gigl_shade_volume_device",
     "gigl_depth_buffer_device", "gigl_combine_device", "gigl_debug_check_layout", "gigl_scene_layout",
+    "gigl_trace_closest_noalloc_device",
 ]
 
 
@@ -78,6 +79,7 @@ def lib():
         L.gigl_scene_export_tree.argtypes = [vp, vp, vp]
         L.gigl_trace_closest_device.argtypes = [vp, vp, vp, u64, vp, vp]
         L.gigl_trace_closest.argtypes = [vp, vp, vp, u64, vp]
+        L.gigl_trace_closest_noalloc_device.argtypes = [vp, vp, vp, u64, vp, vp]
         L.gigl_scene_layout.argtypes = [vp, vp]
         L.gigl_trace_any_device.argtypes = [vp, vp, vp, u64, vp, vp]
         L.gigl_trace_any.argtypes = [vp, vp, vp, u64, vp]
@@ -269,6 +271,10 @@ class Scene:
     # ---- device-pointer calls (ints from torch.Tensor.data_ptr()) ----
     def trace_closest_device(self, o_ptr, d_ptr, n, hits_ptr, stream=0):
         _check(lib().gigl_trace_closest_device(self.h, o_ptr, d_ptr, n, hits_ptr, stream))
+
+    def trace_closest_noalloc_device(self, o_ptr, d_ptr, n, hits_ptr, stream=0):
+        """trace_closest_device without any allocation (static device scratch; see include/gigl_rt.h)."""
+        _check(lib().gigl_trace_closest_noalloc_device(self.h, o_ptr, d_ptr, n, hits_ptr, stream))
 
     def trace_any_device(self, o_ptr, d_ptr, n, bits_ptr, stream=0):
         _check(lib().gigl_trace_any_device(self.h, o_ptr, d_ptr, n, bits_ptr, stream))

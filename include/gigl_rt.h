@@ -109,6 +109,20 @@ int gigl_trace_any_device(const gigl_scene* s, const void* o_tmin, const void* d
                           uint64_t* occluded_bits, void* stream);
 int gigl_trace_any(const gigl_scene* s, const float* o_tmin, const float* d_tmax, uint64_t n,
                    uint64_t* occluded_bits);
+/* gigl_trace_closest_device for callers that cannot allocate (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE.  Same inputs,
+ * same outputs, bit for bit; the call allocates nothing (no hipMalloc / hipMallocAsync / hipFree, no
+ * allocating library routine): its work counter and the spill area of the traversal stacks live in a
+ * 24 MiB array that is part of the library's device image (one copy per GPU, held until the process
+ * ends), located once per device in gigl_scene_create.  The launch is held to 256 workgroups (one
+ * per CU), which that array is sized for, so large batches run slower than through
+ * gigl_trace_closest_device.  n > GIGL_NOALLOC_MAX_RAYS fails with GIGL_ERR_TOO_LARGE.  Every call on
+ * a GPU shares that GPU's array: calls that overlap on one GPU (two streams, two host threads, two
+ * scenes on the same device) RACE; issue them in stream order on one stream. */
+#define GIGL_NOALLOC_MAX_RAYS (1u << 24)
+int gigl_trace_closest_noalloc_device(const gigl_scene* s, const void* o_tmin, const void* d_tmax, uint64_t n,
+                                      gigl_hit* hits, void* stream);
+
 /* Single-ray convenience call with Scene::trace semantics (one launch; host pointers).
  * normal_out (optional) receives the normal as Scene::trace leaves it: normalized for
  * closest-hit rays, unnormalized cross(e0,e1) for visibility rays.  range_out (optional)
