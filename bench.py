@@ -1,20 +1,28 @@
 #!/usr/bin/env python3
 """bench.py — throughput of the ray-query hot path on MI355X.
 
-Workload (BASELINE.json configs[2], the one the 1 Grays/s target is quoted on): the synthetic
-tessellated Cornell scene S(158) = 998,560 triangles, and 2^24 incoherent cosine-weighted
-diffuse-bounce rays per GPU, traced closest-hit through the reference's k-d tree semantics.
-A "step" is one closest-hit pass over the whole ray batch, rays and tree resident in HBM.
-
-N > 1 (one process per GPU, launched by torch.distributed.run): the tree is replicated, every
-rank traces its own 2^24-ray shard (weak scaling: N=8 is configs[3]'s 128M rays) and the 16-byte
-hit records are gathered to rank 0 over RCCL behind the next step's traversal (two hit buffers).
+--config bounce (default; the driver's run)
+  N = 1: BASELINE.json configs[2], the configuration the 1 Grays/s target is quoted on: the synthetic
+  tessellated Cornell scene S(158) = 998,560 triangles and 2^24 incoherent cosine-weighted
+  diffuse-bounce rays, traced closest-hit through the reference's k-d tree semantics.  A "step" is
+  one closest-hit pass over the whole ray batch, rays and tree resident in HBM.
+  N > 1 (one process per GPU, launched by torch.distributed.run): BASELINE.json configs[3]: S(500) =
+  10,000,000 triangles, 2^27 rays in all (RAY_SEED_128M), split into contiguous ranges
+  (gigl_amd.shard.shard_range), tree replicated, no data-path collective; the 16-byte hit records are
+  gathered to rank 0 over RCCL behind the next step's traversal (gigl_amd.shard.ShardedTracer).
+  Total work is fixed as N grows: "scaling": "strong".  `--gpus 1 --tess 500 --total-rays-log2 27`
+  runs the N = 1 point of that series.
+--config cornell_shadow   BASELINE.json configs[1]: Cornell box, 1024^2 primary closest-hit rays (fused
+  generator) + one any-hit shadow ray per (hit pixel, VPL) for the 150 golden VPLs (~152 M pairs).
+--config transmittance    BASELINE.json configs[4]: calcTransm (8-interval ray march through the 64^3
+  density volume) of the same ~152 M shadow segments.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -24,7 +32,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+L2_PEAK_GBS = 34500.0   # same guide: aggregate L2 bandwidth, ~34.5 TB/s
 
 
 def parse():
@@ -32,15 +41,66 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--tess", type=int, default=158, help="k of scene S(k); 158 -> 998,560 triangles")
-    ap.add_argument("--rays-log2", type=int, default=24, help="rays per GPU = 2^this")
+    ap.add_argument("--config", default="bounce", choices=["bounce", "cornell_shadow", "transmittance"])
+    ap.add_argument("--tess", type=int, default=None,
+                    help="k of scene S(k); default 158 (998,560 triangles) at N = 1, 500 (10 M) at N > 1")
+    ap.add_argument("--rays-log2", type=int, default=None, help="rays per GPU = 2^this (weak scaling)")
+    ap.add_argument("--total-rays-log2", type=int, default=None,
+                    help="rays over all GPUs = 2^this, contiguous shards (strong scaling; default 27 at N > 1)")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the RCCL gather of hit records")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--extras", action="store_true", help="also time any-hit and the Cornell configs (N=1)")
+    ap.add_argument("--extras", action="store_true", help="also time any-hit and the Cornell passes (N=1)")
     ap.add_argument("--sample-parity", dest="full_parity", action="store_false",
-                    help="check only the CPU-timed sample (2^21 rays) against the oracle instead of the whole batch")
+                    help="check only the CPU-timed sample against the oracle instead of the whole batch")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (gigl_set_option)")
     return ap.parse_args()
+
+
+def host_info(O=None):
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    info = {"cpu_model": model, "os_cpu_count": os.cpu_count()}
+    if O is not None:
+        info["omp_get_max_threads"] = O.max_threads()
+    return info
+
+
+def git_head():
+    try:
+        return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"],
+                                       stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        return None
+
+
+def traffic_from_profiles(key, layout):
+    """HBM-side bytes per launch from the committed PMC passes (profiles/traffic.json), with where the
+    number comes from: bench.py cannot collect counters itself, so this is NOT measured by this run."""
+    tp = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        tj = json.load(open(tp))
+    except Exception:
+        return None, None
+    ent = tj.get(key) if isinstance(tj.get(key), dict) else None
+    if ent is None and key == "bounce" and "trace_closest_hbm_bytes_per_launch" in tj:   # round-1 file
+        ent = {"hbm_bytes_per_launch": tj["trace_closest_hbm_bytes_per_launch"], "layout": tj.get("layout"),
+               "source": tj.get("source", "profiles/r01_v8_pmc.json"), "commit": tj.get("commit")}
+    if ent is None or (ent.get("layout") is not None and ent.get("layout") != layout):
+        return None, None
+    src = {"file": "profiles/traffic.json", "from": ent.get("source"), "commit": ent.get("commit"),
+           "fetch_size_bytes": ent.get("fetch_size_bytes"), "tcc_miss_per_ray": ent.get("tcc_miss_per_ray"),
+           "note": "constant from a committed rocprofv3 --pmc pass of the same command, not measured by this run"}
+    return ent.get("hbm_bytes_per_launch"), src
+
+
+def kernel_name(layout, closest=True, gen="explicit rays"):
+    return "trace_kernel<%s, %s, %s>" % ("triples" if layout == 2 else "pairs", "closest" if closest else "any", gen)
 
 
 def main():
@@ -52,7 +112,7 @@ def main():
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
     import torch
     import torch.distributed as dist
-    from gigl_amd import rt, scene_io as S, synth
+    from gigl_amd import rt, scene_io as S, shard, synth
 
     n_dev = torch.cuda.device_count()
     dev_index = local_rank % max(n_dev, 1)
@@ -65,78 +125,61 @@ def main():
     for kv in args.opt:
         k, v = kv.split("=")
         rt.set_option(k, int(v))
+    if args.config != "bounce":
+        if world > 1:
+            raise SystemExit("--config %s is a single-GPU configuration" % args.config)
+        out = cornell_config(args, torch, rt, S, device)
+        print(json.dumps(out), flush=True)
+        return
 
-    # ---- inputs (not timed): scene, tree, rays ----
+    # ---- workload ----
+    strong = args.total_rays_log2 is not None or (world > 1 and args.rays_log2 is None)
+    tess = args.tess if args.tess is not None else (158 if world == 1 and not strong else 500)
+    if strong:
+        n_total = 1 << (args.total_rays_log2 if args.total_rays_log2 is not None else 27)
+        seed = synth.RAY_SEED_128M
+    else:
+        n_total = (1 << (args.rays_log2 if args.rays_log2 is not None else 24)) * world
+        seed = synth.RAY_SEED_16M if world == 1 else synth.RAY_SEED_128M
+    lo, hi = shard.shard_range(n_total, world, rank)
+    n = hi - lo
+
+    # ---- inputs (not timed): scene, tree, this rank's rays ----
     t0 = time.time()
     cv, ct, _, _ = S.load_obj(os.path.join(ROOT, "tests", "golden", "cornell_box.obj"))
-    V, T = synth.tessellate(cv, ct, args.tess)
+    V, T = synth.tessellate(cv, ct, tess)
     scene = rt.Scene(V, T, device=dev_index, **S.KD_PARAMS)
     st = scene.stats()
-    n = 1 << args.rays_log2
-    ro, rd = synth.bounce_rays(V, T, n, synth.RAY_SEED_16M if world == 1 else synth.RAY_SEED_128M,
-                               first=rank * n)
+    layout = scene.layout()
+    gen_threads = max(1, min(16, (os.cpu_count() or 1) // max(world, 1)))
+    ro, rd = synth.bounce_rays(V, T, n, seed, first=lo, n_threads=gen_threads)
     d_o = torch.from_numpy(ro).to(device)
     d_d = torch.from_numpy(rd).to(device)
-    d_hits = torch.empty((n, 4), dtype=torch.int32, device=device)
     setup_s = time.time() - t0
     stream = torch.cuda.current_stream()
     sh = stream.cuda_stream
 
-    # N > 1: step i's 16-byte hit records go to rank 0 on a second stream while step i+1 traverses
-    # (two hit buffers).  Every timed step's gather completes inside the timed region; only the last
-    # one is exposed.  One traversal launch per step: splitting a step into chunks to pipeline inside
-    # it costs ~0.7 ms of drain per extra launch of the persistent kernel.
-    gather = world > 1 and not args.no_gather
-    comm_stream = torch.cuda.Stream(device=device) if gather else None
-    hit_bufs = [d_hits, torch.empty_like(d_hits)] if gather else [d_hits]
-    gathered = None
-    if gather and rank == 0:
-        gathered = [torch.empty((n, 4), dtype=torch.int32, device=device) for _ in range(world)]
-    host_gather = gather and backend != "nccl"
-    pending = {}
-    step_no = [0]
-
-    def step():
-        i = step_no[0]
-        step_no[0] += 1
-        buf = hit_bufs[i % len(hit_bufs)]
-        if gather and (i - 2) in pending:
-            pending.pop(i - 2).wait()      # the gather that last read this buffer (stream-level wait)
+    def trace_fn(buf):
         scene.trace_closest_device(d_o.data_ptr(), d_d.data_ptr(), n, buf.data_ptr(), sh)
-        if not gather:
-            return
-        ev = torch.cuda.Event()
-        ev.record(stream)
-        with torch.cuda.stream(comm_stream):
-            comm_stream.wait_event(ev)
-            if host_gather:   # rehearsal backend (gloo): through host memory, synchronous
-                src_h = buf.cpu()
-                dst = [torch.empty_like(src_h) for _ in range(world)] if rank == 0 else None
-                dist.gather(src_h, dst, dst=0)
-            else:
-                pending[i] = dist.gather(buf, gathered if rank == 0 else None, dst=0, async_op=True)
 
-    def drain():
-        for k in sorted(pending):
-            pending.pop(k).wait()
-        if gather:
-            stream.wait_stream(comm_stream)
+    tracer = shard.ShardedTracer(torch, dist if world > 1 else None, world, rank, n_total, device, trace_fn,
+                                 gather=not args.no_gather, backend=backend)
 
     def barrier():
-        drain()
+        tracer.drain()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step()
+        tracer.step()
     barrier()
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     t_start = time.perf_counter()
     for i in range(args.steps):
         ev0[i].record(stream)
-        step()
+        tracer.step()
         ev1[i].record(stream)
     barrier()
     elapsed = time.perf_counter() - t_start
@@ -146,22 +189,64 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     ms_per_step = elapsed * 1e3 / args.steps
-    total_rays = n * world * args.steps
-    value = total_rays / elapsed / 1e6
+    value = n_total * args.steps / elapsed / 1e6
+
+    # ---- N > 1, not timed: the gathered records of every rank's range against a trace of the same rays
+    # on rank 0's own GPU (first 2^16 rays of each range), and rank 0's rate on its shard with the other
+    # GPUs idle (the same scene on one GPU: what an efficiency has to be read against) ----
+    gather_check = None
+    alone = None
+    if world > 1:
+        full = tracer.result()
+        if rank == 0 and full is not None:
+            bad, checked = 0, 0
+            for r, (rlo, rhi) in enumerate(tracer.ranges):
+                m = min(1 << 16, rhi - rlo)
+                xo, xd = synth.bounce_rays(V, T, m, seed, first=rlo)
+                t_o, t_d = torch.from_numpy(xo).to(device), torch.from_numpy(xd).to(device)
+                ref = torch.empty((m, 4), dtype=torch.int32, device=device)
+                scene.trace_closest_device(t_o.data_ptr(), t_d.data_ptr(), m, ref.data_ptr(), sh)
+                torch.cuda.synchronize()
+                bad += int((ref.cpu() != full[rlo:rlo + m].cpu()).any(1).sum())
+                checked += m
+            gather_check = {"rays_checked": checked, "records_differing": bad,
+                            "how": "first 2^16 rays of every rank's range re-traced on rank 0's GPU"}
+        del full
+        dist.barrier()
+        if rank == 0:
+            buf = tracer.bufs[0]
+            trace_fn(buf)
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream)
+            for _ in range(3):
+                trace_fn(buf)
+            b.record(stream)
+            torch.cuda.synchronize()
+            alone = {"mrays_s": round(n * 3 / a.elapsed_time(b) / 1e3, 2), "rays": int(n),
+                     "what": "rank 0 tracing its own shard of the same scene while the other GPUs idle"}
+        dist.barrier()
 
     out = None
     if rank == 0:
-        hits = hit_bufs[(step_no[0] - 1) % len(hit_bufs)].cpu().numpy().view(rt.HIT_DTYPE).reshape(-1)
+        hits = tracer.local_hits().cpu().numpy().view(rt.HIT_DTYPE).reshape(-1)
         # size-independent sanity at full size: every reported hit lies inside its ray's range
         hit_mask = hits["tri_id"] != rt.GIGL_MISS
         assert (hits["tri_id"][hit_mask] < len(T)).all() and (hits["t"][hit_mask] > 0).all()
-        cpu = None
-        parity = None
-        bytes_per_ray = None
-        mean_nodes = mean_tris = None
-        if not args.no_cpu_baseline and world == 1:
+        cpu = parity = bytes_per_ray = mean_nodes = mean_tris = None
+        counters_from = None
+        hinfo = host_info()
+        if not args.no_cpu_baseline:
             from oracle import oracle_py as O
-            ora = O.OracleScene(V, T, **S.KD_PARAMS)
+            hinfo = host_info(O)
+            # S(158): the oracle builds its own tree (15-20 s serial); S(500): it traverses the engine's
+            # exported tree (the serial build would take minutes)
+            if tess <= 200:
+                ora = O.OracleScene(V, T, **S.KD_PARAMS)
+                tree_src = "the oracle's own serial build"
+            else:
+                ora = O.OracleScene(V, T, tree=scene.export_tree())
+                tree_src = "the engine's exported tree (oracle build skipped at this size)"
             cores = min(16, os.cpu_count() or 1)
             n1 = min(n, 1 << 18)
             t1 = time.perf_counter()
@@ -171,69 +256,70 @@ def main():
             t1 = time.perf_counter()
             want, cnt = ora.trace_closest(ro[:nm], rd[:nm], counters=True, n_threads=cores)
             cpum = nm / (time.perf_counter() - t1) / 1e6
-            # parity at full size (not timed): the whole batch against the oracle, in slices so the
-            # host copies stay small; the timed sample above is its first slice
+            # parity (not timed): the batch against the oracle, in slices; the timed sample is its first slice.
+            # At N > 1 only rank 0's shard is checked here (the gather check above covers the other ranks).
+            full_n = n if (args.full_parity and world == 1 and n <= (1 << 24)) else nm
             id_mis, rel_max, checked = 0, {"t": 0.0, "u": 0.0, "v": 0.0}, 0
-            for lo in range(0, n if args.full_parity else nm, nm):
-                hi = min(n, lo + nm)
-                w = want if lo == 0 else ora.trace_closest(ro[lo:hi], rd[lo:hi], n_threads=cores)
-                got = hits[lo:hi]
+            for slo in range(0, full_n, nm):
+                shi = min(full_n, slo + nm)
+                w = want if slo == 0 else ora.trace_closest(ro[slo:shi], rd[slo:shi], n_threads=cores)
+                got = hits[slo:shi]
                 same = got["tri_id"] == w["tri_id"]
                 id_mis += int((~same).sum())
                 for k in rel_max:
                     a, b = got[k][same].astype(np.float64), w[k][same].astype(np.float64)
                     rel_max[k] = max(rel_max[k], float((np.abs(a - b) / np.maximum(np.abs(b), 1e-30)).max(initial=0.0)))
-                checked += hi - lo
+                checked += shi - slo
             parity = {"rays_checked": int(checked), "id_mismatches": id_mis, "max_rel_err_t": rel_max["t"],
-                      "max_rel_err_u": rel_max["u"], "max_rel_err_v": rel_max["v"]}
+                      "max_rel_err_u": rel_max["u"], "max_rel_err_v": rel_max["v"], "oracle_tree": tree_src}
             mean_nodes, mean_tris = float(cnt[:, 0].mean()), float(cnt[:, 1].mean())
+            counters_from = "oracle counters on the first 2^%d rays of this run" % int(np.log2(nm))
+            cpu = {"value": round(cpum, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+                   "sample": "first 2^%d rays of the same batch, OpenMP schedule(dynamic) over rays on %d threads; "
+                             "single-thread on the first 2^%d rays: %.4f Mrays/s"
+                             % (int(np.log2(nm)), cores, int(np.log2(n1)), cpu1),
+                   "single_thread_mrays_s": round(cpu1, 4), "threads_used": cores,
+                   "omp_get_max_threads": hinfo.get("omp_get_max_threads"), "cpu_model": hinfo["cpu_model"]}
+        default_workload = tess == 158 and n == (1 << 24) and world == 1
+        if mean_nodes is None and default_workload:
+            mean_nodes, mean_tris = 61.084, 7.717
+            counters_from = "profiles/r01_bench_n1.log (oracle counters of the same workload; the CPU leg was skipped)"
+        if mean_nodes is not None:
             # 32 B ray in + 16 B hit out + 8 B per node visited + 56 B per triangle test
             bytes_per_ray = 32.0 + 16.0 + 8.0 * mean_nodes + 56.0 * mean_tris
-            cpu = {"value": round(cpum, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
-                   "sample": "first 2^%d rays of the same batch, OpenMP schedule(dynamic) over rays; "
-                             "single-thread on the first 2^%d rays: %.4f Mrays/s"
-                             % (int(np.log2(nm)), int(np.log2(n1)), cpu1),
-                   "single_thread_mrays_s": round(cpu1, 4)}
-        default_workload = args.tess == 158 and args.rays_log2 == 24
-        if bytes_per_ray is None and default_workload:
-            # counters measured on the N=1 run of the same workload (profiles/); used when the CPU leg is skipped
-            bytes_per_ray = 32.0 + 16.0 + 8.0 * 61.06 + 56.0 * 7.72
         k_ms = float(np.mean(kern_ms))
-        # per GPU: one launch sequence over this rank's rays (None: a non-default workload without counters)
+        # per GPU: one launch over this rank's rays
         achieved = bytes_per_ray * n / (k_ms * 1e-3) / 1e9 if bytes_per_ray is not None else None
-        layout = 2
-        for kv in args.opt:
-            if kv.startswith("layout="):
-                layout = int(kv.split("=")[1])
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tp) and default_workload:
-            try:
-                tj = json.load(open(tp))
-                if tj.get("layout") == layout:   # counters of the kernel that ran
-                    traffic = tj.get("trace_closest_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic, traffic_src = traffic_from_profiles("bounce" if default_workload else "bounce_s%d" % tess, layout)
+        per_cu, n_cus = scene.launch_info()
         out = {
             "metric": "Mrays/s (incoherent closest-hit)", "value": round(value, 3), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
             "config": {"workload": "S(%d) tessellated Cornell scene, %d triangles, k-d tree %d nodes depth %d; "
-                                   "2^%d incoherent diffuse-bounce closest-hit rays per GPU%s"
-                                   % (args.tess, len(T), st.n_nodes, st.actual_depth, args.rays_log2,
+                                   "%d incoherent diffuse-bounce closest-hit rays %s%s"
+                                   % (tess, len(T), st.n_nodes, st.actual_depth, n_total,
+                                      "in all, contiguous shards" if world > 1 else "on one GPU",
                                       ("; hit records gathered to rank 0 over %s behind the next step's traversal" % backend)
-                                      if gather else ""),
-                       "triangles": int(len(T)), "rays_per_gpu": int(n), "tree_build_ms": round(st.build_ms, 1),
-                       "tree_device_bytes": int(st.device_bytes), "setup_s": round(setup_s, 1)},
+                                      if tracer.gather else ""),
+                       "baseline_config": "configs[3]" if tess == 500 else ("configs[2]" if default_workload else None),
+                       "triangles": int(len(T)), "rays_total": int(n_total), "rays_rank0": int(n),
+                       "tree_build_ms": round(st.build_ms, 1), "tree_device_bytes": int(st.device_bytes),
+                       "device_layout": layout, "setup_s": round(setup_s, 1),
+                       "same_scene_one_gpu": alone, "gather_check": gather_check, "commit": git_head()},
             "roofline": {"bound": "hbm", "achieved": None if achieved is None else round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel": "trace3_kernel<closest>" if layout == 2 else "trace_kernel<closest>",
-                         "kernel_ms": round(k_ms, 4),
+                         "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 5),
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": kernel_name(layout), "kernel_ms": round(k_ms, 4),
+                         "waves_per_simd": per_cu, "workgroups": per_cu * n_cus,
                          "algorithmic_bytes_per_ray": None if bytes_per_ray is None else round(bytes_per_ray, 2),
-                         "mean_nodes_visited": mean_nodes, "mean_triangle_tests": mean_tris},
+                         "mean_nodes_visited": mean_nodes, "mean_triangle_tests": mean_tris,
+                         "counters_source": counters_from},
             "cpu_baseline": cpu,
             "parity": parity,
+            "host": hinfo,
         }
         if args.extras and world == 1:
             out["extras"] = extras(torch, rt, S, scene, d_o, d_d, n, device)
@@ -244,11 +330,192 @@ def main():
     scene.close()
 
 
+def cornell_inputs(torch, rt, S, device):
+    """Cornell box scene, camera, the golden 150-VPL set's positions and the fog volume (needs the oracle
+    only for the density field, which is an INPUT: the reference's df.3dt payload)."""
+    from oracle import oracle_py as O
+    cv, ct, mats, _ = S.load_obj(os.path.join(ROOT, "tests", "golden", "cornell_box.obj"))
+    cs = rt.Scene(cv, ct, device=device.index, **S.KD_PARAMS)
+    cam = rt.camera_setup(S.CAM_POS, S.CAM_DIR, S.CAM_UP, S.CAM_HFOV, 1024, 1024)
+    vp = np.load(os.path.join(ROOT, "tests", "golden", "vpl_set.npz"))["vpls"]
+    lights = np.ascontiguousarray(vp.view(np.float32).reshape(len(vp), -1)[:, :3]).astype(np.float32)
+    dens = O.make_density((64, 64, 64), 12.0, 1.0)
+    box = cs.bbox().copy()
+    box[4] = min(box[4], np.float32(S.MAX_FOG_HEIGHT))
+    fog = rt.FogVolume(dens, box, S.ABS_K, S.SCA_K)
+    return dict(verts=cv, tris=ct, mats=mats, scene=cs, cam=cam, vpls=vp, lights=lights, dens=dens, box=box, fog=fog)
+
+
+def cornell_config(args, torch, rt, S, device):
+    """configs[1] (cornell_shadow) and configs[4] (transmittance) as driver-runnable lines."""
+    from oracle import oracle_py as O
+    t0 = time.time()
+    ci = cornell_inputs(torch, rt, S, device)
+    cs, cam, lights, fog = ci["scene"], ci["cam"], ci["lights"], ci["fog"]
+    nl = len(lights)
+    npix = 1024 * 1024
+    stream = torch.cuda.current_stream()
+    sh = stream.cuda_stream
+    po = torch.empty((npix, 4), dtype=torch.float32, device=device)
+    pd = torch.empty((npix, 4), dtype=torch.float32, device=device)
+    ph = torch.empty((npix, 4), dtype=torch.int32, device=device)
+    dl = torch.from_numpy(lights).to(device)
+    npair = npix * nl
+    bits = torch.zeros((npair + 63) // 64, dtype=torch.int64, device=device)
+    tr = torch.empty(npair, dtype=torch.float32, device=device) if args.config == "transmittance" else None
+    cs.gen_primary_rays_device(cam, 1024, 0, npix, po.data_ptr(), pd.data_ptr(), sh)
+    cs.trace_primary_device(cam, 1024, 0, npix, ph.data_ptr(), sh)
+    torch.cuda.synchronize()
+    nhit = int((ph[:, 0] != -1).sum().item())
+    layout = cs.layout()
+    setup_s = time.time() - t0
+    shadow = args.config == "cornell_shadow"
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+
+    def step(e=None):
+        if shadow:   # the whole of configs[1]: primary closest-hit, then the shadow pairs
+            cs.trace_primary_device(cam, 1024, 0, npix, ph.data_ptr(), sh)
+        if e:
+            e[0].record(stream)
+        if shadow:
+            cs.shadow_batch_device(po.data_ptr(), pd.data_ptr(), ph.data_ptr(), npix, dl.data_ptr(), nl, bits.data_ptr(),
+                                   stream=sh)
+        else:
+            cs.shadow_batch_device(po.data_ptr(), pd.data_ptr(), ph.data_ptr(), npix, dl.data_ptr(), nl, None, fog=fog,
+                                   transm_ptr=tr.data_ptr(), stream=sh)
+        if e:
+            e[1].record(stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    for i in range(args.steps):
+        step(ev[i])
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t_start
+    k_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))   # the dominant kernel alone
+    ms_per_step = elapsed * 1e3 / args.steps
+    units = (npix + nhit * nl) if shadow else nhit * nl
+    value = units * args.steps / elapsed / 1e6
+
+    # ---- oracle on a bounded sample of pixels (every 64th: 16,384 pixels x 150 lights), same inputs:
+    # parity, the exact work counters the algorithmic bytes are defined on, and the CPU rate ----
+    hinfo = host_info(O)
+    cpu = parity = None
+    sums = None
+    sel = np.arange(0, npix, 64)
+    if not args.no_cpu_baseline:
+        ora = O.OracleScene(ci["verts"], ci["tris"], **S.KD_PARAMS)
+        cores = min(16, os.cpu_count() or 1)
+        so, sd = O.primary_rays(cam, 1024, 0, npix)
+        so, sd = so[sel], sd[sel]
+        hh = ph.cpu().numpy().view(rt.HIT_DTYPE).reshape(-1)[sel]
+        fog_o = O.Fog(ci["dens"], ci["box"], fog.ext_k)
+        t1 = time.perf_counter()
+        if shadow:
+            w_hits = ora.trace_closest(so, sd, n_threads=cores)
+            occ, _, sums = ora.shadow_batch_fused(so, sd, w_hits, lights, fog=None, n_threads=cores)
+            cpu_units = len(sel) + int(sums[0])
+        else:
+            _, w_tr = ora.shadow_batch(so, sd, hh, lights, fog=fog_o, want_transm=True, n_threads=cores)
+            cpu_units = int((hh["tri_id"] != rt.GIGL_MISS).sum()) * nl
+        cpu_s = time.perf_counter() - t1
+        idx = (sel[:, None].astype(np.int64) * nl + np.arange(nl)[None, :]).reshape(-1)
+        if shadow:
+            got_bits = rt.unpack_bits(bits.cpu().numpy().view(np.uint64), npair)[idx].reshape(len(sel), nl)
+            want01 = np.where(occ == 0xFF, 0, occ)
+            parity = {"pairs_checked": int(want01.size), "bit_mismatches": int((got_bits != want01).sum()),
+                      "primary_id_mismatches": int((hh["tri_id"] != w_hits["tri_id"]).sum())}
+        else:
+            got_tr = tr.cpu().numpy()[idx].reshape(len(sel), nl)
+            rel = np.abs(got_tr.astype(np.float64) - w_tr) / np.maximum(np.abs(w_tr), 1e-30)
+            parity = {"pairs_checked": int(w_tr.size), "max_rel_err": float(rel.max()), "tolerance": 1e-5}
+        cpu = {"value": round(cpu_units / cpu_s / 1e6, 4), "unit": "Mrays/s" if shadow else "Msegments/s",
+               "cores": cores, "kind": "port", "threads_used": cores,
+               "sample": "every 64th pixel of the same image (16,384 pixels) x %d lights, OpenMP over pixels on %d "
+                         "threads, %.1f s" % (nl, cores, cpu_s),
+               "omp_get_max_threads": hinfo.get("omp_get_max_threads"), "cpu_model": hinfo["cpu_model"]}
+    per_cu, n_cus = cs.launch_info()
+    if shadow:
+        # SURVEY.md §8(d) on the reference's layouts, for the kernel that GENERATES its rays: nothing is read
+        # per ray; per pair 1/8 B out + 8 B per node visited + 56 B per triangle test (exact oracle counters on
+        # the sample), plus the primary ray and hit record of the point (48 B) once per n_lights pairs.
+        if sums is not None:
+            nodes_pp, tests_pp = float(sums[1]) / float(sums[0]), float(sums[2]) / float(sums[0])
+            bpp = 0.125 + 8.0 * nodes_pp + 56.0 * tests_pp + 48.0 / nl
+            achieved = bpp * nhit * nl / (k_ms * 1e-3) / 1e9
+        else:
+            nodes_pp = tests_pp = bpp = achieved = None
+        roof = {"bound": "hbm", "achieved": None if achieved is None else round(achieved, 2), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "kernel": kernel_name(layout, False, "shadow-pair generator"), "kernel_ms": round(k_ms, 4),
+                "waves_per_simd": per_cu, "algorithmic_bytes_per_pair": None if bpp is None else round(bpp, 3),
+                "mean_nodes_visited": nodes_pp, "mean_triangle_tests": tests_pp,
+                "counters_source": "oracle counters on the sampled pairs of this run",
+                "note": "Cornell's whole structure (151 nodes, 40 triangles: 3.8 KB) is cache-resident: HBM sees only "
+                        "the 1/8 B per pair out and the per-point inputs, so this fraction prices the ALGORITHMIC "
+                        "bytes of the reference's layouts, not DRAM traffic; the kernel is bound by divergent "
+                        "L1/LDS-latency chains and vector ALU issue (DESIGN.md §4.1)"}
+        metric = "Mrays/s (closest-hit + shadow any-hit)"
+        wl = ("Cornell box (40 triangles, 151 nodes), 1024^2 primary closest-hit rays (fused generator) + %d any-hit "
+              "shadow rays (%d hit pixels x %d golden VPLs, fused generator)" % (nhit * nl, nhit, nl))
+    else:
+        # SURVEY.md §8(d), C5: HBM bytes are the 4 B out per segment (the generator reads 48 B per POINT); the volume
+        # is L2-resident, so the bound that matters is L2: 9 samples x one 8-byte corner brick per segment.
+        bpp = 4.0 + 48.0 / nl
+        achieved = bpp * nhit * nl / (k_ms * 1e-3) / 1e9
+        l2 = 72.0 * nhit * nl / (k_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "kernel": "transm_shadow_kernel", "kernel_ms": round(k_ms, 4),
+                "algorithmic_bytes_per_segment": round(bpp, 3),
+                "samples_per_s_G": round(9.0 * nhit * nl / (k_ms * 1e-3) / 1e9, 2),
+                "l2": {"achieved": round(l2, 1), "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": round(l2 / L2_PEAK_GBS, 4),
+                       "bytes_per_segment": 72, "what": "9 trilinear samples x one 8-byte corner brick (2.2 MB table, L2-resident)"},
+                "note": "vector-ALU bound: ~100 instructions per trilinear sample (three IEEE divides of the "
+                        "box normalisation, eight byte->unorm conversions, seven lerps with contraction off)"}
+        metric = "Msegments/s (shadow-ray transmittance, 8-interval ray march)"
+        wl = ("Cornell box, calcTransm (8 intervals, 9 samples, 64^3 u8 density) of %d shadow segments "
+              "(%d hit pixels x %d golden VPLs, generated in the kernel)" % (nhit * nl, nhit, nl))
+    out = {"metric": metric, "value": round(value, 3), "unit": "Mrays/s" if shadow else "Msegments/s", "n_gpus": 1,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": wl, "baseline_config": "configs[1]" if shadow else "configs[4]",
+                      "pairs": int(nhit * nl), "hit_pixels": nhit, "n_lights": nl, "device_layout": layout,
+                      "setup_s": round(setup_s, 1), "commit": git_head()},
+           "roofline": roof, "cpu_baseline": cpu, "parity": parity, "host": hinfo}
+    if args.extras:
+        # the two passes and the fused pass (occlusion first, march only the visible pairs) side by side
+        tr2 = torch.empty(npair, dtype=torch.float32, device=device)
+
+        def timeit(fn, reps=3):
+            fn()
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream)
+            for _ in range(reps):
+                fn()
+            b.record(stream)
+            torch.cuda.synchronize()
+            return a.elapsed_time(b) / reps
+        args_ = (po.data_ptr(), pd.data_ptr(), ph.data_ptr(), npix, dl.data_ptr(), nl)
+        out["extras"] = {
+            "shadow_any_hit_ms": round(timeit(lambda: cs.shadow_batch_device(*args_, bits.data_ptr(), stream=sh)), 3),
+            "transmittance_all_pairs_ms": round(timeit(lambda: cs.shadow_batch_device(*args_, None, fog=fog, transm_ptr=tr2.data_ptr(), stream=sh)), 3),
+            "fused_bits_and_visible_transmittance_ms": round(timeit(lambda: cs.shadow_batch_fused_device(*args_, bits.data_ptr(), fog, tr2.data_ptr(), stream=sh)), 3),
+            "occluded_fraction": round(float(rt.unpack_bits(bits.cpu().numpy().view(np.uint64), npair).sum()) / max(nhit * nl, 1), 4)}
+    fog.close()
+    cs.close()
+    return out
+
+
 def extras(torch, rt, S, scene, d_o, d_d, n, device):
-    """Untimed-by-the-driver side measurements: any-hit on the same batch, Cornell configs 2 and 5."""
+    """Untimed-by-the-driver side measurements on the bounce batch and the Cornell passes."""
     from oracle import oracle_py as O
     res = {}
-    sh = torch.cuda.current_stream().cuda_stream
+    stream = torch.cuda.current_stream()
+    sh = stream.cuda_stream
 
     def timeit(fn, reps=3):
         fn()
@@ -276,11 +543,12 @@ def extras(torch, rt, S, scene, d_o, d_d, n, device):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / reps
     res["closest_hit_two_streams_mrays_s"] = round(n / dt / 1e6, 2)
+    ms = timeit(lambda: scene.trace_closest_noalloc_device(d_o.data_ptr(), d_d.data_ptr(), n, h2[0].data_ptr(), sh))
+    res["closest_hit_noalloc_entry_mrays_s"] = round(n / ms / 1e3, 2)
     del h2
-    # Cornell: 1024^2 primary + x150 shadow (+ transmittance)
-    cv, ct, _, _ = S.load_obj(os.path.join(ROOT, "tests", "golden", "cornell_box.obj"))
-    cs = rt.Scene(cv, ct, device=device.index, **S.KD_PARAMS)
-    cam = rt.camera_setup(S.CAM_POS, S.CAM_DIR, S.CAM_UP, S.CAM_HFOV, 1024, 1024)
+    # Cornell passes
+    ci = cornell_inputs(torch, rt, S, device)
+    cs, cam, fog, vp, mats = ci["scene"], ci["cam"], ci["fog"], ci["vpls"], ci["mats"]
     npix = 1024 * 1024
     po = torch.empty((npix, 4), dtype=torch.float32, device=device)
     pd = torch.empty((npix, 4), dtype=torch.float32, device=device)
@@ -288,34 +556,14 @@ def extras(torch, rt, S, scene, d_o, d_d, n, device):
     cs.gen_primary_rays_device(cam, 1024, 0, npix, po.data_ptr(), pd.data_ptr(), sh)
     ms = timeit(lambda: cs.trace_primary_device(cam, 1024, 0, npix, ph.data_ptr(), sh))
     res["cornell_primary_mrays_s"] = round(npix / ms / 1e3, 2)
-    rng = np.random.default_rng(5)
-    lights = np.stack([rng.uniform(5, 550, 150), rng.uniform(5, 545, 150), rng.uniform(5, 555, 150)], 1).astype(np.float32)
-    dl = torch.from_numpy(lights).to(device)
-    npair = npix * 150
-    sb = torch.zeros((npair + 63) // 64, dtype=torch.int64, device=device)
-    ms = timeit(lambda: cs.shadow_batch_device(po.data_ptr(), pd.data_ptr(), ph.data_ptr(), npix, dl.data_ptr(), 150,
-                                               sb.data_ptr(), stream=sh), reps=2)
-    nhit = int((ph[:, 0] != -1).sum().item())
-    res["cornell_shadow_pairs"] = nhit * 150
-    res["cornell_shadow_mrays_s"] = round(nhit * 150 / ms / 1e3, 2)
-    dens = O.make_density((64, 64, 64), 12.0, 1.0)
-    box = cs.bbox().copy()
-    box[4] = min(box[4], np.float32(S.MAX_FOG_HEIGHT))
-    fog = rt.FogVolume(dens, box, S.ABS_K, S.SCA_K)
-    tr = torch.empty(npair, dtype=torch.float32, device=device)
-    ms = timeit(lambda: cs.shadow_batch_device(po.data_ptr(), pd.data_ptr(), ph.data_ptr(), npix, dl.data_ptr(), 150,
-                                               None, fog=fog, transm_ptr=tr.data_ptr(), stream=sh), reps=2)
-    res["cornell_transmittance_msegments_s"] = round(nhit * 150 / ms / 1e3, 2)
     pi = torch.empty((64, 1024, 1024), dtype=torch.float32, device=device)
     ms = timeit(lambda: cs.compute_pi_density_device(fog, cam, 1024, 1024, pi.data_ptr(), sh), reps=2)
     res["compute_pi_density_1024_ms"] = round(ms, 3)   # reference: 3.1 s on 8 CPU threads
     # one frame of the software shading stage (Surface.frag + tone mapping) over the Cornell config:
     # 1 primary light + the golden 150-VPL set, visibility and transmittance from the shadow batch
-    vp = np.load(os.path.join(ROOT, "tests", "golden", "vpl_set.npz"))["vpls"]
     ppls = np.zeros((1, 8), np.float32)
     ppls[0, :3], ppls[0, 4:7] = S.PRIM_PL_POS, S.PRIM_PL_INTENS
-    l151 = np.concatenate([ppls[:, :3], vp.view(np.float32)[:, :3]]).astype(np.float32)
-    _, _, mats, _ = S.load_obj(os.path.join(ROOT, "tests", "golden", "cornell_box.obj"))
+    l151 = np.concatenate([ppls[:, :3], ci["lights"]]).astype(np.float32)
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
     d_l, d_ppl, d_vpl, d_mat = up(l151), up(ppls), up(vp.view(np.int32)), up(mats)
     npair = npix * 151
@@ -363,8 +611,8 @@ def extras(torch, rt, S, scene, d_o, d_d, n, device):
 
     def frame():   # frame 0 of the reference's render loop, every pass
         cs.trace_primary_device(cam, 1024, 0, npix, ph.data_ptr(), sh)
-        cs.shadow_batch_device(po.data_ptr(), pd.data_ptr(), ph.data_ptr(), npix, d_l.data_ptr(), 151, sb.data_ptr(),
-                               fog=fog, transm_ptr=tr.data_ptr(), stream=sh)
+        cs.shadow_batch_fused_device(po.data_ptr(), pd.data_ptr(), ph.data_ptr(), npix, d_l.data_ptr(), 151,
+                                     sb.data_ptr(), fog, tr.data_ptr(), stream=sh)
         shade()
         volume()
         combine()

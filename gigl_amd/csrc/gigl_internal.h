@@ -95,47 +95,6 @@ __device__ __forceinline__ bool box_intersect(const BoxF& b, const RayReg& r, fl
     return false;
 }
 
-struct TraceParams {
-    const uint2* nodes;
-    uint2 root;           // the root node's two words (slot 0 of nodes)
-    const uint4* recs;    // triple layout: the same buffer as 16-byte records
-    uint4 root_rec;       // triple layout: record 0
-    const unsigned* leaf_ids;
-    const float4* tris;   // kTriStride float4 per triangle: (p0.xyz,e0.x) (e0.yz,e1.xy) (e1.z,mat,-,-) (-)
-    BoxF box;
-    unsigned n;
-    unsigned* counter;
-    uint4* spill;         // (t_split, w0, w1, -) entries beyond the LDS stack
-    unsigned spill_stride;
-    int refill_thresh;
-    int any_atomic;
-    unsigned chunk;   // rays a wave takes from the global counter per atomic (multiple of 64)
-    unsigned guided;  // 0: fixed chunks; else requests shrink to remaining / guided near the end
-    int t_exit;       // T-phase repeats while at least this many lanes are still descending
-    // GEN 0: explicit rays
-    const float4* o_tmin;
-    const float4* d_tmax;
-    // GEN 1: primary rays
-    float cam[12];
-    unsigned res_x, first;
-    // GEN 2: shadow pairs
-    const float4* prim_o;
-    const float4* prim_d;
-    const uint4* prim_hits;
-    const float* lights;
-    unsigned n_lights;
-    // GEN 3: (point, light) pairs from explicit points (x, y, z, valid)
-    const float4* points;
-    // outputs
-    uint4* hits;
-    unsigned long long* bits;
-    unsigned long long* stats;   // STATS build only: 12 counters
-    float2* ranges;              // optional: the ray's (t_min, t_max) as KdTree::intersect leaves them
-    float4* hit_tri;             // optional, with ranges: the first 48 bytes of the hit triangle's record per ray
-    unsigned reset_counter;      // single-wave launches only: the wave zeroes the work counter on exit
-    const unsigned* perm;        // optional (GEN 0): work item i traces ray perm[i] (ray regrouping)
-};
-
 // getPrimaryRay(x + 0.5, y + 0.5), Camera.cpp:65-68; normalize = v * (1/sqrt(dot)) (GLM).
 __device__ __forceinline__ void primary_ray(const float* cam, unsigned res_x, unsigned pix, float& dx, float& dy,
                                             float& dz) {
@@ -227,6 +186,47 @@ __device__ __forceinline__ float calc_transm(const FogParams& F, float px, float
     return expf(-(total * dt));
 }
 
+struct TraceParams {
+    const uint2* nodes;
+    uint2 root;           // the root node's two words (slot 0 of nodes)
+    const uint4* recs;    // triple layout: the same buffer as 16-byte records
+    uint4 root_rec;       // triple layout: record 0
+    const unsigned* leaf_ids;
+    const float4* tris;   // kTriStride float4 per triangle: (p0.xyz,e0.x) (e0.yz,e1.xy) (e1.z,mat,-,-) (-)
+    BoxF box;
+    unsigned n;
+    unsigned* counter;
+    uint4* spill;         // (t_split, w0, w1, -) entries beyond the LDS stack
+    unsigned spill_stride;
+    int refill_thresh;
+    int any_atomic;
+    unsigned chunk;   // rays a wave takes from the global counter per atomic (multiple of 64)
+    unsigned guided;  // 0: fixed chunks; else requests shrink to remaining / guided near the end
+    int t_exit;       // T-phase repeats while at least this many lanes are still descending
+    // GEN 0: explicit rays
+    const float4* o_tmin;
+    const float4* d_tmax;
+    // GEN 1: primary rays
+    float cam[12];
+    unsigned res_x, first;
+    // GEN 2: shadow pairs
+    const float4* prim_o;
+    const float4* prim_d;
+    const uint4* prim_hits;
+    const float* lights;
+    unsigned n_lights;
+    // GEN 3: (point, light) pairs from explicit points (x, y, z, valid)
+    const float4* points;
+    // outputs
+    uint4* hits;
+    unsigned long long* bits;
+    unsigned long long* stats;   // STATS build only: 12 counters
+    float2* ranges;              // optional: the ray's (t_min, t_max) as KdTree::intersect leaves them
+    float4* hit_tri;             // optional, with ranges: the first 48 bytes of the hit triangle's record per ray
+    unsigned reset_counter;      // single-wave launches only: the wave zeroes the work counter on exit
+    const unsigned* perm;        // optional (GEN 0): work item i traces ray perm[i] (ray regrouping)
+};
+
 // ---- 3-vectors for the shading stage (operation order as the oracle's V3) ------------------
 struct F3 { float x, y, z; };
 __device__ __forceinline__ F3 f3(float x, float y, float z) { return F3{x, y, z}; }
@@ -271,6 +271,8 @@ struct gigl_scene {
     bool triples = false;          // d_nodes holds the triple layout (trace3_kernel)
     unsigned* d_leaf_ids = nullptr;
     float4* d_tris = nullptr;
+    size_t nb_nodes = 0, nb_leaf = 0, nb_tris = 0;   // bytes of the three device arrays
+    bool replica = false;          // a copy made by scene_clone_to_device: tree.nodes / leaf_prim_ids are empty
     gd::BoxF box;
     gigl_tree_stats stats;
     int layout = 2;                // device layout in use (kd_layout.h): 0, 1 or 2 (2 may fall back to 1 at create)
@@ -292,6 +294,11 @@ struct gigl_fog {
 };
 
 namespace gd {
+
+// A copy of a device scene on another device (or the same one): the flattened tree and the triangle
+// records are copied device to device, the host tree's vectors are not duplicated.  Defined in
+// gigl_rt.hip, used by the multi-device entry points (gigl_multi.hip).
+int scene_clone_to_device(const gigl_scene* src, int device, gigl_scene** out);
 
 struct DeviceGuard {
     int prev = -1;

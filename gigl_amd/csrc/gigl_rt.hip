@@ -667,6 +667,50 @@ __global__ void __launch_bounds__(256) transm_shadow_kernel(FogParams F, TracePa
     }
 }
 
+// calcTransm for the pairs the any-hit pass found unoccluded only (the shader's order,
+// Surface.frag:250-256).  37 % of the Cornell pairs are occluded; skipping them lane by lane would
+// save nothing (a wave marches as long as its slowest lane), so every wave compacts: it walks its
+// block of pairs 64 at a time, writes 0 for the occluded ones, queues the indices of the others in
+// LDS (ballot + prefix count) and marches whenever 64 are queued, every lane busy.
+constexpr unsigned kVisPairsPerWave = 2048;
+__global__ void __launch_bounds__(256) transm_visible_kernel(FogParams F, TraceParams P, const unsigned long long* bits,
+                                                             float* out) {
+    __shared__ unsigned s_q[4][128];
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    unsigned* q = s_q[wave];
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const unsigned n_blocks = (P.n + kVisPairsPerWave - 1) / kVisPairsPerWave;
+    auto march = [&](unsigned idx) {
+        ShadowSeg s;
+        float tr = 1.0f;   // points whose primary ray missed
+        if (shadow_segment(P, idx, s)) tr = calc_transm(F, s.px, s.py, s.pz, s.wx, s.wy, s.wz, s.dist_sq);
+        out[idx] = tr;
+    };
+    for (unsigned blk = blockIdx.x * 4u + wave; blk < n_blocks; blk += gridDim.x * 4u) {
+        const unsigned base = blk * kVisPairsPerWave;
+        unsigned count = 0;
+        for (unsigned c = 0; c < kVisPairsPerWave; c += 64u) {
+            const unsigned idx = base + c + lane;
+            if (base + c >= P.n) break;
+            const unsigned long long word = bits[(base + c) >> 6];   // base is a multiple of 64: one word per round
+            const bool valid = idx < P.n;
+            const bool occluded = (word >> lane) & 1ull;
+            if (valid && occluded) out[idx] = 0.0f;   // nothing arrives from an occluded light
+            const unsigned long long m = __ballot(valid && !occluded);
+            if (valid && !occluded) q[count + __popcll(m & lt)] = idx;
+            count += __popcll(m);
+            if (count >= 64u) {
+                march(q[lane]);
+                const unsigned rest = count - 64u;
+                const unsigned moved = lane < rest ? q[64u + lane] : 0u;
+                if (lane < rest) q[lane] = moved;
+                count = rest;
+            }
+        }
+        if (lane < count) march(q[lane]);
+    }
+}
+
 __global__ void __launch_bounds__(256) eps_kernel(const float* t, unsigned n, float* out) {
     for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) out[i] = rescaled_eps(t[i]);
 }
@@ -892,6 +936,23 @@ int launch_trace(const gigl_scene* s, TraceParams& P, hipStream_t st, const ExtW
     return rc;
 }
 
+// Per-scene resources on the scene's device (current when called): gigl_trace_one's staging,
+// workspace and stream, and this device's address of the no-allocation scratch array.
+int scene_device_resources(gigl_scene* s) {
+    HIP_TRY(hipHostMalloc((void**)&s->h_one, 7 * sizeof(float4), hipHostMallocMapped));
+    HIP_TRY(hipHostGetDevicePointer((void**)&s->d_one, s->h_one, 0));
+    const size_t one_ws_bytes = 256 + (size_t)64 * kSpillDepth * sizeof(uint4);
+    HIP_TRY(hipMalloc(&s->one_ws, one_ws_bytes));
+    HIP_TRY(hipMemset(s->one_ws, 0, 256));
+    HIP_TRY(hipStreamCreateWithFlags(&s->one_stream, hipStreamNonBlocking));
+    hipMemPool_t pool;   // keep the stream-ordered pool's memory between calls
+    if (hipDeviceGetDefaultMemPool(&pool, s->device) == hipSuccess) {
+        uint64_t thr = UINT64_MAX;
+        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr);
+    }
+    return scratch_for_device(s->device, &s->scratch);
+}
+
 int check_batch(const gigl_scene* s, const void* a, const void* b, uint64_t n, const void* out) {
     if (!s) return fail(GIGL_ERR_INVALID, "scene is NULL");
     if (s->device == GIGL_DEVICE_NONE) return fail(GIGL_ERR_NO_DEVICE, "host-only scene: no device to trace on");
@@ -903,6 +964,53 @@ int check_batch(const gigl_scene* s, const void* a, const void* b, uint64_t n, c
 
 
 }  // namespace
+
+int gd::scene_clone_to_device(const gigl_scene* src, int device, gigl_scene** out) {
+    *out = nullptr;
+    if (!src || src->device == GIGL_DEVICE_NONE) return fail(GIGL_ERR_INVALID, "clone needs a device scene");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev)
+        return fail(GIGL_ERR_INVALID, "device index out of range");
+    gigl_scene* s = new gigl_scene();
+    s->device = device;
+    s->replica = true;
+    s->n_tris = src->n_tris;
+    s->n_cus = src->n_cus;
+    for (int a = 0; a < 3; ++a) { s->tree.box_min[a] = src->tree.box_min[a]; s->tree.box_max[a] = src->tree.box_max[a]; }
+    s->tree.max_depth = src->tree.max_depth; s->tree.actual_depth = src->tree.actual_depth;
+    s->tree.leaf_count = src->tree.leaf_count; s->tree.prims_in_leaves = src->tree.prims_in_leaves;
+    s->root = src->root; s->root_rec = src->root_rec; s->triples = src->triples; s->layout = src->layout;
+    s->box = src->box; s->stats = src->stats;
+    s->nb_nodes = src->nb_nodes; s->nb_leaf = src->nb_leaf; s->nb_tris = src->nb_tris;
+    DeviceGuard g(device);
+    auto cleanup = [&]() {
+        if (s->d_nodes) (void)hipFree(s->d_nodes);
+        if (s->d_leaf_ids) (void)hipFree(s->d_leaf_ids);
+        if (s->d_tris) (void)hipFree(s->d_tris);
+        if (s->h_one) (void)hipHostFree(s->h_one);
+        if (s->one_ws) (void)hipFree(s->one_ws);
+        if (s->one_stream) (void)hipStreamDestroy(s->one_stream);
+        delete s;
+    };
+    hipError_t e = g.ok ? hipSuccess : hipErrorInvalidDevice;
+    hipDeviceProp_t prop;
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
+    if (e == hipSuccess) s->n_cus = prop.multiProcessorCount;
+    if (e == hipSuccess) e = hipMalloc((void**)&s->d_nodes, s->nb_nodes);
+    if (e == hipSuccess && s->nb_leaf) e = hipMalloc((void**)&s->d_leaf_ids, s->nb_leaf);
+    if (e == hipSuccess) e = hipMalloc((void**)&s->d_tris, s->nb_tris);
+    // the replicated tree travels device to device (over xGMI between two GPUs), not through the host
+    if (e == hipSuccess) e = hipMemcpyPeer(s->d_nodes, device, src->d_nodes, src->device, s->nb_nodes);
+    if (e == hipSuccess && s->nb_leaf) e = hipMemcpyPeer(s->d_leaf_ids, device, src->d_leaf_ids, src->device, s->nb_leaf);
+    if (e == hipSuccess) e = hipMemcpyPeer(s->d_tris, device, src->d_tris, src->device, s->nb_tris);
+    if (e != hipSuccess) {
+        cleanup();
+        return fail(GIGL_ERR_HIP, std::string("scene replica: ") + hipGetErrorString(e));
+    }
+    if (scene_device_resources(s) != GIGL_OK) { cleanup(); return GIGL_ERR_HIP; }
+    *out = s;
+    return GIGL_OK;
+}
 
 extern "C" {
 
@@ -1061,12 +1169,6 @@ int gigl_scene_create(const float* verts, uint32_t n_verts, const uint32_t* tris
     hipError_t e = hipGetDeviceProperties(&prop, device);
     if (e != hipSuccess) { delete s; return fail(GIGL_ERR_HIP, "hipGetDeviceProperties failed"); }
     s->n_cus = prop.multiProcessorCount;
-    // keep the stream-ordered pool's memory between calls
-    hipMemPool_t pool;
-    if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess) {
-        uint64_t thr = UINT64_MAX;
-        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr);
-    }
     // ---- device tree: same topology, re-addressed for the kernels (kd_layout.h) ----
     gigl::DeviceTree dtree;
     if (layout == 2 && !gigl::layout_triples(s->tree, dtree)) layout = 1;   // beyond the record encoding: fall back
@@ -1104,13 +1206,7 @@ int gigl_scene_create(const float* verts, uint32_t n_verts, const uint32_t* tris
     CREATE_TRY(hipMalloc((void**)&s->d_nodes, nb_nodes));
     if (!ids_inline) CREATE_TRY(hipMalloc((void**)&s->d_leaf_ids, nb_leaf));
     CREATE_TRY(hipMalloc((void**)&s->d_tris, nb_tris));
-    CREATE_TRY(hipHostMalloc((void**)&s->h_one, 7 * sizeof(float4), hipHostMallocMapped));
-    CREATE_TRY(hipHostGetDevicePointer((void**)&s->d_one, s->h_one, 0));
-    const size_t one_ws_bytes = 256 + (size_t)64 * kSpillDepth * sizeof(uint4);
-    CREATE_TRY(hipMalloc(&s->one_ws, one_ws_bytes));
-    CREATE_TRY(hipMemset(s->one_ws, 0, 256));
-    CREATE_TRY(hipStreamCreateWithFlags(&s->one_stream, hipStreamNonBlocking));
-    if (scratch_for_device(device, &s->scratch) != GIGL_OK) { cleanup(); return GIGL_ERR_HIP; }
+    if (scene_device_resources(s) != GIGL_OK) { cleanup(); return GIGL_ERR_HIP; }
     CREATE_TRY(hipMemcpy(s->d_nodes, dn.data(), dn.size() * 8, hipMemcpyHostToDevice));
     if (!ids_inline && !dtree.ids.empty())
         CREATE_TRY(hipMemcpy(s->d_leaf_ids, dtree.ids.data(), dtree.ids.size() * 4, hipMemcpyHostToDevice));
@@ -1121,6 +1217,7 @@ int gigl_scene_create(const float* verts, uint32_t n_verts, const uint32_t* tris
     s->box = BoxF{s->tree.box_min[0], s->tree.box_min[1], s->tree.box_min[2],
                   s->tree.box_max[0], s->tree.box_max[1], s->tree.box_max[2]};
     s->stats.device_bytes = nb_nodes + nb_leaf + nb_tris;
+    s->nb_nodes = nb_nodes; s->nb_leaf = nb_leaf; s->nb_tris = nb_tris;
     *out = s;
     return GIGL_OK;
 }
@@ -1243,6 +1340,18 @@ int gigl_trace_closest_noalloc_device(const gigl_scene* s, const void* o_tmin, c
     P.hits = (uint4*)hits;
     const ExtWorkspace ext = {s->scratch, kNoAllocBlocks};
     return launch_trace<false, 0>(s, P, (hipStream_t)stream, &ext);
+}
+
+int gigl_debug_launch_info(const gigl_scene* s, int* blocks_per_cu, int* n_cus) {
+    if (!s || !blocks_per_cu || !n_cus) return fail(GIGL_ERR_INVALID, "NULL argument");
+    if (s->device == GIGL_DEVICE_NONE) return fail(GIGL_ERR_NO_DEVICE, "host-only scene");
+    DeviceGuard g(s->device);
+    auto kern = s->triples ? trace_kernel<true, false, 0, 8, kBlock> : trace_kernel<false, false, 0, 8, kBlock>;
+    int q = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, kern, kBlock, 0));
+    *blocks_per_cu = q;
+    *n_cus = s->n_cus;
+    return GIGL_OK;
 }
 
 int gigl_scene_layout(const gigl_scene* s, int* layout_out) {
@@ -1375,9 +1484,9 @@ int gigl_trace_primary_device(const gigl_scene* s, const float cam[12], int res_
     return launch_trace<false, 1>(s, P, (hipStream_t)stream);
 }
 
-int gigl_shadow_batch_device(const gigl_scene* s, const void* prim_o_tmin, const void* prim_d_tmax,
-                             const gigl_hit* prim_hits, uint64_t n_pts, const float* lights, uint32_t n_lights,
-                             uint64_t* occluded_bits, const gigl_fog* fog, float* transm, void* stream) {
+static int shadow_batch(const gigl_scene* s, const void* prim_o_tmin, const void* prim_d_tmax,
+                        const gigl_hit* prim_hits, uint64_t n_pts, const float* lights, uint32_t n_lights,
+                        uint64_t* occluded_bits, const gigl_fog* fog, float* transm, void* stream, bool fused) {
     if (!s) return fail(GIGL_ERR_INVALID, "scene is NULL");
     if (s->device == GIGL_DEVICE_NONE) return fail(GIGL_ERR_NO_DEVICE, "host-only scene: no device to trace on");
     const uint64_t n = n_pts * (uint64_t)n_lights;
@@ -1396,6 +1505,18 @@ int gigl_shadow_batch_device(const gigl_scene* s, const void* prim_o_tmin, const
     P.lights = lights;
     P.n_lights = n_lights;
     P.bits = (unsigned long long*)occluded_bits;
+    if (occluded_bits && transm && fused) {   // visibility first, then the march of the visible pairs only
+        int rc = launch_trace<true, 2>(s, P, (hipStream_t)stream);
+        if (rc != GIGL_OK) return rc;
+        P.tris = s->d_tris;
+        const uint64_t waves = (n + kVisPairsPerWave - 1) / kVisPairsPerWave;
+        const uint64_t cap = (uint64_t)s->n_cus * 8;
+        const unsigned grid = (unsigned)std::min<uint64_t>(std::max<uint64_t>((waves + 3) / 4, 1), cap);
+        hipLaunchKernelGGL(transm_visible_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, fog->fp, P,
+                           (const unsigned long long*)occluded_bits, transm);
+        HIP_TRY(hipGetLastError());
+        return GIGL_OK;
+    }
     if (occluded_bits) {
         int rc = launch_trace<true, 2>(s, P, (hipStream_t)stream);
         if (rc != GIGL_OK) return rc;
@@ -1407,6 +1528,21 @@ int gigl_shadow_batch_device(const gigl_scene* s, const void* prim_o_tmin, const
         HIP_TRY(hipGetLastError());
     }
     return GIGL_OK;
+}
+
+int gigl_shadow_batch_device(const gigl_scene* s, const void* prim_o_tmin, const void* prim_d_tmax,
+                             const gigl_hit* prim_hits, uint64_t n_pts, const float* lights, uint32_t n_lights,
+                             uint64_t* occluded_bits, const gigl_fog* fog, float* transm, void* stream) {
+    return shadow_batch(s, prim_o_tmin, prim_d_tmax, prim_hits, n_pts, lights, n_lights, occluded_bits, fog, transm,
+                        stream, false);
+}
+
+int gigl_shadow_batch_fused_device(const gigl_scene* s, const void* prim_o_tmin, const void* prim_d_tmax,
+                                   const gigl_hit* prim_hits, uint64_t n_pts, const float* lights, uint32_t n_lights,
+                                   uint64_t* occluded_bits, const gigl_fog* fog, float* transm, void* stream) {
+    if (!occluded_bits || !transm || !fog) return fail(GIGL_ERR_INVALID, "the fused shadow batch writes bits and transmittance: both outputs and the fog are required");
+    return shadow_batch(s, prim_o_tmin, prim_d_tmax, prim_hits, n_pts, lights, n_lights, occluded_bits, fog, transm,
+                        stream, true);
 }
 
 int gigl_shadow_points_device(const gigl_scene* s, const float* points, uint64_t n_pts, const float* lights,

@@ -28,7 +28,9 @@ SYMBOLS = [
     "gigl_set_option", "gigl_debug_last_stats", "gigl_compute_pi_density_device", "gigl_shade_surface_device",
     "gigl_tonemap_device", "gigl_volume_samples_device", "gigl_shadow_points_device", "gigl_shade_volume_device",
     "gigl_depth_buffer_device", "gigl_combine_device", "gigl_debug_check_layout", "gigl_scene_layout",
-    "gigl_trace_closest_noalloc_device",
+    "gigl_trace_closest_noalloc_device", "gigl_multi_create", "gigl_multi_destroy", "gigl_multi_device_count",
+    "gigl_multi_trace_closest_device", "gigl_multi_trace_closest", "gigl_shadow_batch_fused_device",
+    "gigl_debug_launch_info",
 ]
 
 
@@ -81,6 +83,12 @@ def lib():
         L.gigl_trace_closest.argtypes = [vp, vp, vp, u64, vp]
         L.gigl_trace_closest_noalloc_device.argtypes = [vp, vp, vp, u64, vp, vp]
         L.gigl_scene_layout.argtypes = [vp, vp]
+        L.gigl_debug_launch_info.argtypes = [vp, vp, vp]
+        L.gigl_multi_create.argtypes = [vp, vp, i, vp]
+        L.gigl_multi_destroy.argtypes = [vp]
+        L.gigl_multi_device_count.argtypes = [vp, vp]
+        L.gigl_multi_trace_closest_device.argtypes = [vp, vp, vp, u64, vp]
+        L.gigl_multi_trace_closest.argtypes = [vp, vp, vp, u64, vp]
         L.gigl_trace_any_device.argtypes = [vp, vp, vp, u64, vp, vp]
         L.gigl_trace_any.argtypes = [vp, vp, vp, u64, vp]
         L.gigl_trace_one.argtypes = [vp, vp, vp, f, f, i, vp, vp, vp, vp]
@@ -88,6 +96,7 @@ def lib():
         L.gigl_gen_primary_rays_device.argtypes = [vp, vp, i, u64, u64, vp, vp, vp]
         L.gigl_trace_primary_device.argtypes = [vp, vp, i, u64, u64, vp, vp]
         L.gigl_shadow_batch_device.argtypes = [vp, vp, vp, vp, u64, vp, u32, vp, vp, vp, vp]
+        L.gigl_shadow_batch_fused_device.argtypes = [vp, vp, vp, vp, u64, vp, u32, vp, vp, vp, vp]
         L.gigl_fog_create.argtypes = [vp, vp, vp, f, i, i, vp]
         L.gigl_fog_destroy.argtypes = [vp]
         L.gigl_transmittance_device.argtypes = [vp, vp, vp, u64, vp, vp]
@@ -232,6 +241,12 @@ class Scene:
         _check(lib().gigl_scene_layout(self.h, C.byref(v)))
         return v.value
 
+    def launch_info(self):
+        """(workgroups per CU = waves per SIMD, CUs) of the closest-hit kernel of this scene's layout."""
+        a, b = C.c_int(0), C.c_int(0)
+        _check(lib().gigl_debug_launch_info(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def check_layout(self, layout=1, treelet_levels=3):
         """Rebuilds the device layout on the host and checks it against the tree; returns its bytes."""
         n = C.c_uint64(0)
@@ -317,6 +332,50 @@ class Scene:
                             transm_ptr=None, stream=0):
         _check(lib().gigl_shadow_batch_device(self.h, o_ptr, d_ptr, hits_ptr, n_pts, lights_ptr, n_lights,
                                               bits_ptr, fog.h if fog is not None else None, transm_ptr, stream))
+
+
+    def shadow_batch_fused_device(self, o_ptr, d_ptr, hits_ptr, n_pts, lights_ptr, n_lights, bits_ptr, fog,
+                                  transm_ptr, stream=0):
+        """Occlusion bits and, for the unoccluded pairs only, calcTransm, in one pass (0 where occluded)."""
+        _check(lib().gigl_shadow_batch_fused_device(self.h, o_ptr, d_ptr, hits_ptr, n_pts, lights_ptr, n_lights,
+                                                    bits_ptr, fog.h, transm_ptr, stream))
+
+
+class MultiDeviceScene:
+    """A scene replicated over a list of devices of one node (gigl_multi_*): contiguous ray ranges per
+    device, hit records gathered to devices[0] (device pointers) or to the host (numpy)."""
+
+    def __init__(self, scene, devices):
+        devs = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        _check(lib().gigl_multi_create(scene.h, devs, len(devices), C.byref(h)))
+        self.h = h
+        self.scene = scene   # replica 0 is the scene itself: keep it alive
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().gigl_multi_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def device_count(self):
+        n = C.c_int(0)
+        _check(lib().gigl_multi_device_count(self.h, C.byref(n)))
+        return n.value
+
+    def trace(self, o_tmin, d_tmax):
+        ro, rd = _f32(o_tmin).reshape(-1, 4), _f32(d_tmax).reshape(-1, 4)
+        hits = np.zeros(len(ro), HIT_DTYPE)
+        _check(lib().gigl_multi_trace_closest(self.h, _p(ro), _p(rd), len(ro), _p(hits)))
+        return hits
+
+    def trace_closest_device(self, o_ptr, d_ptr, n, hits_ptr):
+        _check(lib().gigl_multi_trace_closest_device(self.h, o_ptr, d_ptr, n, hits_ptr))
 
 
 class FogVolume:

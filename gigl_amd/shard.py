@@ -2,11 +2,11 @@
 
 Rays are independent, so the path shards with no data-path collective: the tree is replicated,
 rank r traces the contiguous ray range shard_range(n, world, r), and the only exchange is the
-gather of the hit buffers to rank 0 (16 B per closest-hit ray, 1 bit per any-hit ray).  The
-gather is issued chunk by chunk behind the traversal so the xGMI transfer of chunk i overlaps
-the traversal of chunk i+1 (bench.py).
+gather of the hit buffers to rank 0 (16 B per closest-hit ray).  ShardedTracer is that step, used
+as it stands by bench.py (RCCL, one rank per GPU) and by tests/test_multi_rank_gloo.py (gloo, CPU
+tensors, a stand-in tracer): step i's gather runs behind step i+1's traversal (two hit buffers, a
+second stream), one traversal launch per step.
 """
-import numpy as np
 
 
 def shard_range(n, world, rank):
@@ -18,27 +18,80 @@ def shard_range(n, world, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def chunk_bounds(n, chunks):
-    chunks = max(1, min(int(chunks), max(int(n), 1)))
-    return [(i * int(n)) // chunks for i in range(chunks + 1)]
+class ShardedTracer:
+    """One rank's side of the sharded closest-hit step.
 
-
-def gather_hits(local_hits, n_total, world, rank, dist, dst=0):
-    """Gathers per-rank hit-record arrays (any shard sizes) into ray order on rank `dst`.
-
-    local_hits: torch tensor [m, 4] int32 on the backend's device.  Returns the [n_total, 4]
-    tensor on dst, None elsewhere.  Shards are padded to the largest shard for the collective.
+    trace_fn(buf): traces this rank's rays [lo, hi) into buf[:hi - lo] (a [m_max, 4] int32 tensor on
+    `device`), asynchronously on the current stream when the device is a GPU.  dist is
+    torch.distributed (or None when world == 1); the process group must be initialised.
+    gather=False: no exchange at all (each rank keeps its hits).
+    On a GPU with the nccl (= RCCL) backend the gather of step i is issued on a second stream behind
+    an event and overlaps the traversal of step i + 1; every other combination (CPU tensors, or GPU
+    tensors with gloo: through host memory) gathers synchronously.
     """
-    import torch
-    sizes = [shard_range(n_total, world, r) for r in range(world)]
-    m_max = max(hi - lo for lo, hi in sizes)
-    pad = torch.zeros((m_max, 4), dtype=local_hits.dtype, device=local_hits.device)
-    pad[: local_hits.shape[0]] = local_hits
-    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
-    dist.gather(pad, bufs, dst=dst)
-    if rank != dst:
-        return None
-    out = torch.empty((n_total, 4), dtype=local_hits.dtype, device=local_hits.device)
-    for r, (lo, hi) in enumerate(sizes):
-        out[lo:hi] = bufs[r][: hi - lo]
-    return out
+
+    def __init__(self, torch, dist, world, rank, n_total, device, trace_fn, gather=True, backend="nccl"):
+        self.torch, self.dist, self.world, self.rank = torch, dist, world, rank
+        self.n_total = int(n_total)
+        self.device = torch.device(device)
+        self.trace_fn = trace_fn
+        self.ranges = [shard_range(n_total, world, r) for r in range(world)]
+        self.lo, self.hi = self.ranges[rank]
+        self.m = self.hi - self.lo
+        self.m_max = max(hi - lo for lo, hi in self.ranges)      # the collective wants equal sizes
+        self.gather = bool(gather) and world > 1
+        self.on_gpu = self.device.type == "cuda"
+        self.overlap = self.gather and self.on_gpu and backend == "nccl"
+        new = lambda: torch.zeros((self.m_max, 4), dtype=torch.int32, device=self.device)
+        self.bufs = [new(), new()] if self.gather else [new()]
+        self.gathered = None
+        if self.gather and rank == 0:
+            gdev = self.device if (self.overlap or not self.on_gpu) else torch.device("cpu")
+            self.gathered = [torch.zeros((self.m_max, 4), dtype=torch.int32, device=gdev) for _ in range(world)]
+        self.comm_stream = torch.cuda.Stream(device=self.device) if self.overlap else None
+        self.pending = {}
+        self.i = 0
+
+    def step(self):
+        torch, dist = self.torch, self.dist
+        i = self.i
+        self.i += 1
+        buf = self.bufs[i % len(self.bufs)]
+        if (i - 2) in self.pending:
+            self.pending.pop(i - 2).wait()      # the gather that last read this buffer (stream-level wait on a GPU)
+        self.trace_fn(buf)
+        if not self.gather:
+            return
+        if self.overlap:
+            stream = torch.cuda.current_stream(self.device)
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(ev)
+                self.pending[i] = dist.gather(buf, self.gathered if self.rank == 0 else None, dst=0, async_op=True)
+        else:
+            src = buf.cpu() if self.on_gpu else buf     # gloo rehearsal on a GPU: through host memory
+            dist.gather(src, self.gathered if self.rank == 0 else None, dst=0)
+
+    def drain(self):
+        """Completes every gather issued so far (and orders the current stream behind them)."""
+        for k in sorted(self.pending):
+            self.pending.pop(k).wait()
+        if self.overlap:
+            self.torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
+
+    def local_hits(self):
+        """This rank's records of the last step, [m, 4]."""
+        return self.bufs[(self.i - 1) % len(self.bufs)][: self.m]
+
+    def result(self):
+        """Rank 0, after drain(): the last step's records of ALL rays in ray order, [n_total, 4]
+        (None on other ranks; without a gather, this rank's own records)."""
+        if not self.gather:
+            return self.local_hits() if self.world == 1 or self.rank == 0 else None
+        if self.rank != 0:
+            return None
+        out = self.torch.empty((self.n_total, 4), dtype=self.torch.int32, device=self.gathered[0].device)
+        for r, (lo, hi) in enumerate(self.ranges):
+            out[lo:hi] = self.gathered[r][: hi - lo]
+        return out

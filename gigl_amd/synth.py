@@ -75,14 +75,17 @@ def tessellate(verts, tris, k, amplitude=1.0, seed=SCENE_SEED):
     return np.concatenate(out_v).astype(F32), np.concatenate(out_t).astype(np.uint32)
 
 
-def bounce_rays(verts, tris, n, seed, first=0, chunk=1 << 22):
-    """R(n, seed) rays [first, first+n) as (o_tmin f32[n,4], d_tmax f32[n,4])."""
+def bounce_rays(verts, tris, n, seed, first=0, chunk=1 << 20, n_threads=1):
+    """R(n, seed) rays [first, first+n) as (o_tmin f32[n,4], d_tmax f32[n,4]).  Ray i depends on
+    (seed, first + i) only, so chunks are independent: n_threads > 1 generates them on a thread pool
+    (NumPy releases the GIL in its array loops) with the same result."""
     verts = np.asarray(verts, F32)
     tris = np.asarray(tris, np.uint32)
     n_tris = len(tris)
     ro = np.empty((n, 4), F32)
     rd = np.empty((n, 4), F32)
-    for lo in range(0, n, chunk):
+
+    def one(lo):
         m = min(chunk, n - lo)
         idx = (np.arange(lo, lo + m, dtype=np.uint64) + np.uint64(first))
         c = _hash32((idx & np.uint64(0xFFFFFFFF)).astype(np.uint32) ^ np.uint32(seed))
@@ -119,4 +122,13 @@ def bounce_rays(verts, tris, n, seed, first=0, chunk=1 << 22):
         ro[lo:lo + m, 3] = 0.0
         rd[lo:lo + m, :3] = d
         rd[lo:lo + m, 3] = FLT_MAX
+
+    starts = list(range(0, n, chunk))
+    if n_threads > 1 and len(starts) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=n_threads) as ex:
+            list(ex.map(one, starts))
+    else:
+        for lo in starts:
+            one(lo)
     return ro, rd

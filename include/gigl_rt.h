@@ -109,6 +109,27 @@ int gigl_trace_any_device(const gigl_scene* s, const void* o_tmin, const void* d
                           uint64_t* occluded_bits, void* stream);
 int gigl_trace_any(const gigl_scene* s, const float* o_tmin, const float* d_tmax, uint64_t n,
                    uint64_t* occluded_bits);
+/* Several devices of one node behind one call: the scene's flattened tree and
+ * triangle records are replicated on every device of the list (device to device, over xGMI between
+ * two GPUs), a batch is split into contiguous ray ranges whose sizes differ by at most one, each
+ * device traces its range (one host thread and one stream per device) and the 16-byte hit records
+ * are gathered by direct peer copies, one point-to-point transfer per device: no ring, no reduction.
+ * Extends Scene::trace over a batch (Source/Common/Scene.cpp:234-243); the reference is a single
+ * CPU process and has nothing of the kind.  devices[0] must be the scene's own device (its replica
+ * is the scene itself, which must outlive the handle); a device may appear more than once.
+ * gigl_multi_trace_closest_device: o_tmin, d_tmax and hits are device pointers on devices[0];
+ * gigl_multi_trace_closest: host pointers (each device fetches and returns its own range).  Both are
+ * synchronous and return records identical to gigl_trace_closest_device on the whole batch.  One
+ * batch at a time per handle. */
+typedef struct gigl_multi gigl_multi;
+int gigl_multi_create(const gigl_scene* s, const int* devices, int n_devices, gigl_multi** out);
+int gigl_multi_destroy(gigl_multi* m);
+int gigl_multi_device_count(const gigl_multi* m, int* count);
+int gigl_multi_trace_closest_device(gigl_multi* m, const void* o_tmin, const void* d_tmax, uint64_t n,
+                                    gigl_hit* hits);
+int gigl_multi_trace_closest(gigl_multi* m, const float* o_tmin, const float* d_tmax, uint64_t n,
+                             gigl_hit* hits);
+
 /* gigl_trace_closest_device for callers that cannot allocate (code under HIP graph capture, tight
  * serving loops, harnesses that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE.  Same inputs,
  * same outputs, bit for bit; the call allocates nothing (no hipMalloc / hipMallocAsync / hipFree, no
@@ -154,6 +175,17 @@ int gigl_shadow_batch_device(const gigl_scene* s, const void* prim_o_tmin, const
                              const gigl_hit* prim_hits, uint64_t n_pts, const float* lights,
                              uint32_t n_lights, uint64_t* occluded_bits, const gigl_fog* fog,
                              float* transm, void* stream);
+
+/* The same batch in the shader's own order (Source/Shaders/Surface.frag:250-256, :270-288: the shadow
+ * test first, calcTransm only for visible lights), in one call: the any-hit pass, then a march whose
+ * waves compact the unoccluded pairs of their block (ballot + prefix count into LDS) so that occluded
+ * pairs cost no samples and every marching lane is busy.
+ * Bits as above; transm[pair] = 0 for an occluded pair (nothing arrives from that light), calcTransm
+ * for a visible one, 1.0 for missed points.  Both outputs and the fog are required. */
+int gigl_shadow_batch_fused_device(const gigl_scene* s, const void* prim_o_tmin, const void* prim_d_tmax,
+                                   const gigl_hit* prim_hits, uint64_t n_pts, const float* lights,
+                                   uint32_t n_lights, uint64_t* occluded_bits, const gigl_fog* fog,
+                                   float* transm, void* stream);
 
 /* Software shading stage ("next" row of the scope table): Surface.frag main()
  * (Source/Shaders/Surface.frag:290-343) for one frame over pixels [first, first+n_pts), consuming
@@ -262,6 +294,11 @@ int gigl_debug_check_layout(const gigl_scene* s, int layout, int treelet_levels,
  * L lane-rounds, refills, refilled lanes, sum over rounds of lanes holding a ray; then, on the
  * 100 MHz real-time counter: ~(earliest wave start), latest wave end, sum of wave ends, waves. */
 int gigl_debug_last_stats(uint64_t out[12]);
+
+/* Residency of the explicit-ray closest-hit kernel of this scene's layout: 256-thread workgroups per
+ * CU as the occupancy query reports them (= waves per SIMD: 4 waves per workgroup over 4 SIMDs), and
+ * the CU count the persistent grid is sized with.  Diagnostic; bench.py reports it. */
+int gigl_debug_launch_info(const gigl_scene* s, int* blocks_per_cu, int* n_cus);
 
 /* Tuning knobs (process-wide; read at each launch).  Names and meaning in DESIGN.md. */
 int gigl_set_option(const char* name, int value);

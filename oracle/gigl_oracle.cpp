@@ -729,6 +729,57 @@ void ora_shadow_batch(const ora_scene* s, const float* po, const float* pd, cons
     }
 }
 
+/* The shader's order (Surface.frag:250-256, :270-288): visibility first, calcTransm only for visible
+ * lights.  occluded as ora_shadow_batch; transm = 0 for an occluded pair (nothing arrives from that
+ * light), calcTransm for a visible one, 1.0 for points whose primary ray missed.  sums (optional):
+ * [0] pairs traced, [1] nodes visited, [2] triangle tests, [3] pairs marched - the exact counters the
+ * algorithmic-bytes definition of SURVEY.md 8(d) is stated on. */
+void ora_shadow_batch_fused(const ora_scene* s, const float* po, const float* pd, const void* prim_hits16,
+                            uint64_t n_pts, const float* lights, uint32_t n_lights, uint8_t* occluded,
+                            const ora_fog* fog, float* transm, uint64_t* sums, int n_threads) {
+    const Hit16* H = (const Hit16*)prim_hits16;
+    const int nt = n_threads < 1 ? 1 : n_threads;
+    (void)nt;
+    uint64_t n_pairs = 0, n_nodes = 0, n_tests = 0, n_marched = 0;
+#pragma omp parallel for schedule(dynamic, 64) num_threads(nt) if (nt > 1) reduction(+ : n_pairs, n_nodes, n_tests, n_marched)
+    for (int64_t i = 0; i < (int64_t)n_pts; ++i) {
+        uint8_t* occ = occluded + (size_t)i * n_lights;
+        float* tr = transm ? transm + (size_t)i * n_lights : NULL;
+        const Hit16 h = H[i];
+        if (h.tri_id == 0xFFFFFFFFu) {
+            for (uint32_t l = 0; l < n_lights; ++l) { occ[l] = 0xFF; if (tr) tr[l] = 1.0f; }
+            continue;
+        }
+        const V3 o = v3(po[4 * i], po[4 * i + 1], po[4 * i + 2]);
+        const V3 d = v3(pd[4 * i], pd[4 * i + 1], pd[4 * i + 2]);
+        const V3 p = o + h.t * d;
+        const uint* ix = &s->tris[4 * (size_t)h.tri_id];
+        const V3 pt0 = s->verts[ix[0]];
+        const V3 e0 = s->verts[ix[1]] - pt0, e1 = s->verts[ix[2]] - pt0;
+        V3 N = normalize(cross(e0, e1));
+        if (dot(d, N) > 0.0f) N = -N;
+        for (uint32_t l = 0; l < n_lights; ++l) {
+            const V3 L = v3(lights[3 * l], lights[3 * l + 1], lights[3 * l + 2]);
+            const V3 dirv = L - p;
+            const float dist_sq = dot(dirv, dirv);
+            const float dist = sqrtf(dist_sq);
+            const V3 w = dirv * (1.0f / sqrtf(dist_sq));
+            Ray r = make_ray_offset(p, w, N);
+            r.t_min = 0.0f; r.t_max = dist;
+            const bool blocked = scene_trace(*s, r, true);
+            occ[l] = blocked ? 1 : 0;
+            ++n_pairs; n_nodes += r.nodes_visited; n_tests += r.tri_tests;
+            if (tr) {
+                if (blocked) tr[l] = 0.0f;
+                else { tr[l] = fog ? glsl_calc_transm(*fog, p, w, dist_sq) : 1.0f; ++n_marched; }
+            }
+        }
+    }
+    if (sums) { sums[0] = n_pairs; sums[1] = n_nodes; sums[2] = n_tests; sums[3] = n_marched; }
+}
+
+int ora_max_threads(void) { return omp_get_max_threads(); }
+
 float ora_sample_density(const ora_fog* fog, const float pos[3]) {
     return sample_density(*fog, v3(pos[0], pos[1], pos[2]));
 }

@@ -108,6 +108,17 @@ void ora_shadow_batch(const ora_scene* s, const float* prim_o_tmin, const float*
                       uint32_t n_lights, uint8_t* occluded, const ora_fog* fog, float* transm,
                       int n_threads);
 
+/* The same batch in the shader's order (Source/Shaders/Surface.frag:250-256, :270-288): visibility
+ * first, calcTransm only for visible lights.  transm = 0 for an occluded pair, calcTransm for a
+ * visible one, 1.0 where the primary ray missed.  sums (optional): uint64[4] = pairs traced, nodes
+ * visited, triangle tests, pairs marched (exact work counters). */
+void ora_shadow_batch_fused(const ora_scene* s, const float* prim_o_tmin, const float* prim_d_tmax,
+                            const void* prim_hits16, uint64_t n_pts, const float* lights,
+                            uint32_t n_lights, uint8_t* occluded, const ora_fog* fog, float* transm,
+                            uint64_t* sums, int n_threads);
+/* omp_get_max_threads(): what the cpu_baseline leg of bench.py reports beside its thread count. */
+int ora_max_threads(void);
+
 /* DensityField::sampleDensity (Source/Fog/DensityField.cpp:177-211). */
 float ora_sample_density(const ora_fog* fog, const float pos[3]);
 /* calcTransm + intersectBBox + rayMarch (Source/Shaders/Surface.frag:139-203) with

@@ -65,6 +65,10 @@ def lib():
         L.ora_primary_rays.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
         L.ora_shadow_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
                                        C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.ora_shadow_batch_fused.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
+                                             C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_int]
+        L.ora_max_threads.restype = C.c_int
         L.ora_sample_density.restype = C.c_float
         L.ora_sample_density.argtypes = [C.c_void_p, C.c_void_p]
         L.ora_transmittance.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
@@ -214,6 +218,24 @@ class OracleScene:
         lib().ora_shadow_batch(self.h, _p(ro), _p(rd), _p(hits), n, _p(lights), nl, _p(occ),
                                fog.ref() if fog is not None else None, _p(tr), n_threads)
         return (occ, tr) if want_transm else occ
+
+    def shadow_batch_fused(self, ro, rd, hits, lights, fog=None, n_threads=1):
+        """Visibility first, calcTransm only for visible lights (0 for occluded pairs).  Returns
+        (occluded, transm, sums) with sums = pairs traced, nodes visited, triangle tests, pairs marched."""
+        ro, rd = _f32(ro).reshape(-1, 4), _f32(rd).reshape(-1, 4)
+        hits = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
+        lights = _f32(lights).reshape(-1, 3)
+        n, nl = len(ro), len(lights)
+        occ = np.zeros((n, nl), np.uint8)
+        tr = np.zeros((n, nl), np.float32)
+        sums = np.zeros(4, np.uint64)
+        lib().ora_shadow_batch_fused(self.h, _p(ro), _p(rd), _p(hits), n, _p(lights), nl, _p(occ),
+                                     fog.ref() if fog is not None else None, _p(tr), _p(sums), n_threads)
+        return occ, tr, sums
+
+
+def max_threads():
+    return lib().ora_max_threads()
 
 
 def rescaled_eps(t):

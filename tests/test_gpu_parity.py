@@ -398,6 +398,82 @@ def test_shadow_batch_cornell(gpu_cornell, oracle_cornell, cornell_cam, density,
     fog_g.close()
 
 
+def test_shadow_batch_fused_cornell(gpu_cornell, oracle_cornell, cornell_cam, density, fog_box):
+    """The shader's order (Surface.frag:250-256): visibility first, calcTransm only for the visible
+    pairs, in one pass.  Bits bit-exact; transmittance 0 where occluded, <= 1e-5 relative where
+    visible, 1.0 for missed points; and equal to the two-pass batch wherever the pair is visible."""
+    torch = pytest.importorskip("torch")
+    pix = np.arange(250 * 1024, 760 * 1024, 29, dtype=np.uint64)[:6000]
+    ro = np.concatenate([O.primary_rays(cornell_cam, 1024, int(p), 1)[0] for p in pix])
+    rd = np.concatenate([O.primary_rays(cornell_cam, 1024, int(p), 1)[1] for p in pix])
+    rd[:7, :3] = [0, 0, -1]   # guaranteed misses
+    hits = oracle_cornell.trace_closest(ro, rd)
+    vp = np.load(__import__("os").path.join(__import__("conftest").GOLDEN, "vpl_set.npz"))["vpls"]
+    lights = np.concatenate([[S.PRIM_PL_POS], vp.view(np.float32).reshape(len(vp), -1)[:, :3]]).astype(np.float32)
+    fog_o = O.Fog(density, fog_box, np.float32(S.ABS_K) + np.float32(S.SCA_K))
+    fog_g = rt.FogVolume(density, fog_box, S.ABS_K, S.SCA_K)
+    w_occ, w_tr, sums = oracle_cornell.shadow_batch_fused(ro, rd, hits, lights, fog=fog_o, n_threads=4)
+    n_pts, nl = len(ro), len(lights)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    d_o, d_d, d_l = t(ro), t(rd), t(lights)
+    d_h = torch.from_numpy(hits.view(np.int32).reshape(-1, 4).copy()).cuda()
+    sh = torch.cuda.current_stream().cuda_stream
+    for any_atomic in (-1, 0):
+        try:
+            rt.set_option("any_atomic", any_atomic)
+            bits = torch.zeros((n_pts * nl + 63) // 64, dtype=torch.int64, device="cuda:0")
+            tr = torch.full((n_pts * nl,), -5.0, dtype=torch.float32, device="cuda:0")
+            gpu_cornell.shadow_batch_fused_device(d_o.data_ptr(), d_d.data_ptr(), d_h.data_ptr(), n_pts, d_l.data_ptr(),
+                                                  nl, bits.data_ptr(), fog_g, tr.data_ptr(), stream=sh)
+            torch.cuda.synchronize()
+        finally:
+            rt.set_option("any_atomic", -1)
+        got = rt.unpack_bits(bits.cpu().numpy().view(np.uint64), n_pts * nl).reshape(n_pts, nl)
+        want01 = np.where(w_occ == 0xFF, 0, w_occ)
+        assert np.array_equal(got, want01)
+        got_tr = tr.cpu().numpy().reshape(n_pts, nl)
+        assert (got_tr[want01 == 1] == 0.0).all()                       # nothing arrives from an occluded light
+        assert (got_tr[hits["tri_id"] == rt.GIGL_MISS] == 1.0).all()    # missed points
+        rel = np.abs(got_tr.astype(np.float64) - w_tr) / np.maximum(np.abs(w_tr), 1e-30)
+        assert float(rel[want01 == 0].max()) <= REL_TOL
+    assert int(sums[0]) == int((hits["tri_id"] != rt.GIGL_MISS).sum()) * nl and 0 < int(sums[3]) < int(sums[0])
+    # against the two-pass batch: the same numbers wherever the pair is visible
+    tr2 = torch.zeros(n_pts * nl, dtype=torch.float32, device="cuda:0")
+    gpu_cornell.shadow_batch_device(d_o.data_ptr(), d_d.data_ptr(), d_h.data_ptr(), n_pts, d_l.data_ptr(), nl, None,
+                                    fog=fog_g, transm_ptr=tr2.data_ptr(), stream=sh)
+    torch.cuda.synchronize()
+    two = tr2.cpu().numpy().reshape(n_pts, nl)
+    assert np.array_equal(two[want01 == 0].view(np.uint32), got_tr[want01 == 0].view(np.uint32))
+    fog_g.close()
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0, 0]])
+def test_multi_device_entry_points(s16, devices):
+    """gigl_multi_*: the scene replicated over a device list, contiguous ray ranges, hit records gathered
+    to devices[0] (peer copies) or to the host.  A one-device list is the plain call; a list that
+    repeats device 0 runs the replication, scatter and gather paths on a one-GPU box.  Records equal
+    gigl_trace_closest_device's on the whole batch, bit for bit."""
+    torch = pytest.importorskip("torch")
+    n = 200_003   # ragged over 3 ranges
+    ro, rd = synth.bounce_rays(s16["V"], s16["T"], n, 0x3D1CE5)
+    d_o, d_d = torch.from_numpy(ro).cuda(), torch.from_numpy(rd).cuda()
+    want = torch.empty((n, 4), dtype=torch.int32, device="cuda:0")
+    s16["gpu"].trace_closest_device(d_o.data_ptr(), d_d.data_ptr(), n, want.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    m = rt.MultiDeviceScene(s16["gpu"], devices)
+    assert m.device_count() == len(devices)
+    for n_call in (n, 1000, n):   # a smaller batch in between: the staging buffers are reused
+        got = torch.full((n_call, 4), -3, dtype=torch.int32, device="cuda:0")
+        m.trace_closest_device(d_o.data_ptr(), d_d.data_ptr(), n_call, got.data_ptr())
+        assert torch.equal(got, want[:n_call])
+    host = m.trace(ro, rd)     # host pointers: every device fetches and returns its own range
+    assert np.array_equal(host.view(np.uint32).reshape(-1, 4), want.cpu().numpy().view(np.uint32))
+    assert len(m.trace(ro[:0], rd[:0])) == 0
+    m.close()
+    with pytest.raises(rt.GiglError):
+        rt.MultiDeviceScene(s16["gpu"], [1_000])   # devices[0] must be the scene's device
+
+
 @pytest.mark.parametrize("res", [(96, 64), (1024, 1024)])
 def test_compute_pi_density(gpu_cornell, oracle_cornell, density, fog_box, res):
     """SURVEY.md §8(f).1: DensityField::computePiDensity as one GPU batch (primary closest-hit, then

@@ -167,7 +167,6 @@ def test_shard_ranges():
         assert r[0][0] == 0 and r[-1][1] == n
         assert all(r[i][1] == r[i + 1][0] for i in range(w - 1))
         assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
-    assert shard.chunk_bounds(10, 4) == [0, 2, 5, 7, 10]
     with pytest.raises(ValueError):
         shard.shard_range(5, 2, 2)
 

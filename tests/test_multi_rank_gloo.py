@@ -1,7 +1,8 @@
 """CPU, world_size 2 over gloo: the N > 1 path shards the ray batch into contiguous ranges,
 every rank answers its own range against a replicated tree, and the hit records are gathered
-into ray order on rank 0.  No GPU here, so each rank's tracer is the oracle; what is under test
-is the sharding, padding and gather order that bench.py and a multi-GPU host use."""
+into ray order on rank 0.  No GPU here, so the injected tracer is the oracle; what is under test is
+gigl_amd.shard.ShardedTracer, the class bench.py drives at N > 1: sharding, double buffering, padding
+and gather order, over several steps."""
 import os
 import socket
 import sys
@@ -20,6 +21,14 @@ def _free_port():
     return p
 
 
+STEPS = 3
+
+
+def _batch(synth, V, T, n, step, first=0, count=None):
+    """Step `step` traces its own ray batch, so a stale or mixed-up hit buffer cannot pass."""
+    return synth.bounce_rays(V, T, n if count is None else count, 0x51A7D + step, first=first)
+
+
 def _worker(rank, world, port, n, out_path):
     sys.path.insert(0, ROOT)
     import torch
@@ -33,17 +42,30 @@ def _worker(rank, world, port, n, out_path):
     V, T = synth.tessellate(cv, ct, 4)
     ora = O.OracleScene(V, T, **S.KD_PARAMS)          # replicated tree
     lo, hi = shard.shard_range(n, world, rank)
-    ro, rd = synth.bounce_rays(V, T, hi - lo, 0x51A7D, first=lo)   # this rank's shard only
-    hits = ora.trace_closest(ro, rd)
-    local = torch.from_numpy(hits.view(np.int32).reshape(-1, 4).copy())
-    full = shard.gather_hits(local, n, world, rank, dist, dst=0)
+    step_no = [0]
+
+    def trace_fn(buf):                                # the tracer is injected: here the oracle stands in for the GPU
+        ro, rd = _batch(synth, V, T, n, step_no[0], first=lo, count=hi - lo)   # this rank's shard only
+        hits = ora.trace_closest(ro, rd)
+        buf[: hi - lo] = torch.from_numpy(hits.view(np.int32).reshape(-1, 4).copy())
+        step_no[0] += 1
+
+    # the same class bench.py drives with the HIP engine and RCCL
+    st = shard.ShardedTracer(torch, dist, world, rank, n, "cpu", trace_fn, gather=True, backend="gloo")
+    assert (st.lo, st.hi) == (lo, hi) and not st.overlap
+    results = []
+    for _ in range(STEPS):
+        st.step()
+        st.drain()
+        full = st.result()
+        results.append(None if full is None else full.numpy().copy())
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)          # the bench's max-over-ranks timing reduction
     assert t.item() == world
     if rank == 0:
-        np.save(out_path, full.numpy())
+        np.save(out_path, np.stack(results))
     else:
-        assert full is None
+        assert all(r is None for r in results)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -58,6 +80,19 @@ def test_sharded_trace_and_gather_equals_single_batch(tmp_path, n):
     got = np.load(out).view(np.uint32)
     cv, ct, _, _ = S.load_obj(os.path.join(ROOT, "tests", "golden", "cornell_box.obj"))
     V, T = synth.tessellate(cv, ct, 4)
-    ro, rd = synth.bounce_rays(V, T, n, 0x51A7D)
-    want = O.OracleScene(V, T, **S.KD_PARAMS).trace_closest(ro, rd)
-    assert np.array_equal(got, want.view(np.uint32).reshape(-1, 4))
+    ora = O.OracleScene(V, T, **S.KD_PARAMS)
+    for step in range(STEPS):
+        ro, rd = _batch(synth, V, T, n, step)
+        want = ora.trace_closest(ro, rd)
+        assert np.array_equal(got[step], want.view(np.uint32).reshape(-1, 4)), step
+
+
+def test_shard_ranges_cover_the_batch():
+    from gigl_amd import shard
+    for n in (0, 1, 7, 64, 4099, 1 << 27):
+        for world in (1, 2, 3, 8):
+            r = [shard.shard_range(n, world, k) for k in range(world)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(r[k][1] == r[k + 1][0] for k in range(world - 1))
+            sizes = [hi - lo for lo, hi in r]
+            assert max(sizes) - min(sizes) <= 1
