@@ -10,6 +10,11 @@
 #ifndef GIGL_BRANCHLESS_TRI
 #define GIGL_BRANCHLESS_TRI 0
 #endif
+// Register budget of the traversal kernel: the compiler is told to stay within what 6 waves per SIMD
+// allow (80 VGPRs); 0 leaves the allocation to it.
+#ifndef GIGL_WAVES_PER_EU
+#define GIGL_WAVES_PER_EU 6
+#endif
 #ifndef GIGL_STREAM_HINT
 #define GIGL_STREAM_HINT 1
 #endif
@@ -192,7 +197,8 @@ struct TraceParams {
     const uint4* recs;    // triple layout: the same buffer as 16-byte records
     uint4 root_rec;       // triple layout: record 0
     const unsigned* leaf_ids;
-    const float4* tris;   // kTriStride float4 per triangle: (p0.xyz,e0.x) (e0.yz,e1.xy) (e1.z,mat,-,-) (-)
+    const float4* tris;   // kTriStride float4 per triangle: (p0.xyz,e0.x) (e0.yz,e1.xy) (e1.z,id,mat,-) (-)
+    unsigned blocks_off8;   // leaf triangle blocks (kd_layout.h): where their lines start behind the table, in 8-byte units
     BoxF box;
     unsigned n;
     unsigned* counter;
@@ -271,6 +277,7 @@ struct gigl_scene {
     bool triples = false;          // d_nodes holds the triple layout (trace3_kernel)
     unsigned* d_leaf_ids = nullptr;
     float4* d_tris = nullptr;
+    unsigned blocks_off8 = 0;      // leaf triangle blocks (kd_layout.h) start here in d_tris, in 8-byte units (0: none)
     size_t nb_nodes = 0, nb_leaf = 0, nb_tris = 0;   // bytes of the three device arrays
     bool replica = false;          // a copy made by scene_clone_to_device: tree.nodes / leaf_prim_ids are empty
     gd::BoxF box;

@@ -117,18 +117,29 @@ __device__ __forceinline__ bool fetch_ray(const TraceParams& P, unsigned idx, Ra
     }
 }
 
-// Flattened triangle record, one 64-byte line: (p0.xyz, e0.x) (e0.yz, e1.xy) (e1.z, mat, -, -) (-).
-struct TriRec { float4 a, b; float e1z; };
+// Flattened triangle record: (p0.xyz, e0.x) (e0.yz, e1.xy) (e1.z, id).  In the scene's table a record
+// is one 64-byte line per triangle id (its third float4 continues with the material id); in a leaf's
+// private block (kd_layout.h) it is 40 bytes, three per 128-byte line, 8-byte aligned.
+struct TriRec { float4 a, b; float e1z; unsigned tag; };
+typedef float tri_f4 __attribute__((ext_vector_type(4), aligned(8)));
+typedef float tri_f2 __attribute__((ext_vector_type(2), aligned(8)));
 
 // All three loads are issued before any use: one memory round trip per triangle (left to itself
 // the compiler sinks the p0 load below the det != 0 test, which makes it two).
-__device__ __forceinline__ TriRec load_tri(const float4* __restrict__ tris, unsigned id) {
+__device__ __forceinline__ TriRec load_tri(const char* __restrict__ p) {
     TriRec t;
-    const float4* p = tris + kTriStride * (size_t)id;
-    // plain (cached) loads: the same hint on these costs 60 %, the records live in L2 / Infinity Cache
-    t.a = p[0]; t.b = p[1]; t.e1z = p[2].x;
+    // plain (cached) loads: the nontemporal hint on these costs 60 %, the records live in L2 / Infinity Cache
+    const tri_f4 a = *reinterpret_cast<const tri_f4*>(p), b = *reinterpret_cast<const tri_f4*>(p + 16);
+    const tri_f2 c = *reinterpret_cast<const tri_f2*>(p + 32);
+    t.a = make_float4(a.x, a.y, a.z, a.w); t.b = make_float4(b.x, b.y, b.z, b.w);
+    t.e1z = c.x; t.tag = __float_as_uint(c.y);
     asm volatile("" : "+v"(t.a.x), "+v"(t.a.y), "+v"(t.a.z), "+v"(t.a.w));
     return t;
+}
+// Table and leaf blocks share one allocation, so a triangle record is named by one 32-bit offset in
+// 8-byte units from the table's start, whichever of the two it lives in (32 GB of range).
+__device__ __forceinline__ const char* tri_ptr(const float4* tris, unsigned off8) {
+    return reinterpret_cast<const char*>(tris) + (size_t)off8 * 8u;
 }
 
 // Triangle::intersect, RTBase.cpp:150-177.  Edges are stored precomputed (pt1-pt0, pt2-pt0 are
@@ -216,8 +227,13 @@ __device__ __forceinline__ void spill_load(const uint4* p, unsigned& a, unsigned
 // a record still to be loaded (unit = w1 >> 3).
 //
 // A lane without a ray always holds a leaf, so the T-phase test needs no have_ray term.
+#if GIGL_WAVES_PER_EU
+#define GIGL_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(STACK_N == 8 ? GIGL_WAVES_PER_EU : 1, 8)))
+#else
+#define GIGL_WAVES_ATTR
+#endif
 template <bool TRIPLES, bool ANY, int GEN, int STACK_N, int BLOCK, bool STATS = false>
-__global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
+__global__ void __launch_bounds__(BLOCK) GIGL_WAVES_ATTR trace_kernel(const TraceParams P) {
     // stack entry = (t_split, the far child's two words): the far child is in registers when the
     // entry is pushed, so a pop costs no global load (pairs) or at most the record's (triples)
     __shared__ uint2 s_stack[STACK_N * BLOCK];     // (t_split, w1)
@@ -469,7 +485,7 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
                     else rec = make_uint4(payload >> 2, 0u, 0u, kind == 1u ? (3u | (1u << 2)) : 3u);
                     lvl = 0u;
                 }
-                n_prims = rec.w >> 2;
+                n_prims = (rec.w >> 2) & 0x1FFFFFFFu;   // bit 31: the leaf reads its private triangle block
             } else {
                 const unsigned kind = (nd.y >> 29) & 3u;
                 n_prims = kind == 3u ? (nd.y & kLeafPayload) : kind;
@@ -480,10 +496,19 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
                 if (m_l) { ++st_l_rounds; st_l_lanes += __popcll(m_l); }
             }
             if (leaf_i < n_prims) {
-                unsigned id0, id1;
+                unsigned id0 = 0u, id1 = 0u;   // table mode: triangle ids; block mode: record offsets in 8-byte units
                 const bool two = leaf_i + 1 < n_prims;
+                bool in_block = false;
                 if constexpr (TRIPLES) {
-                    if (n_prims <= 3u) {
+                    in_block = (int)rec.w < 0;
+                    if (in_block) {
+                        // record i of the block: line i / 3, 40-byte slot i % 3; read in list order, so a
+                        // leaf costs ceil(n / 3) consecutive lines and no id list
+                        const unsigned i1 = two ? leaf_i + 1u : leaf_i;
+                        const unsigned base8 = P.blocks_off8 + rec.x * 16u;
+                        id0 = base8 + (leaf_i / 3u) * 16u + (leaf_i % 3u) * 5u;
+                        id1 = base8 + (i1 / 3u) * 16u + (i1 % 3u) * 5u;
+                    } else if (n_prims <= 3u) {
                         id0 = leaf_i == 0u ? rec.x : rec.z;
                         id1 = rec.y;
                     } else {
@@ -500,10 +525,11 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const TraceParams P) {
                         id1 = nd.y & kLeafPayload;
                     }
                 }
-                const TriRec t0 = load_tri(P.tris, id0);
-                const TriRec t1 = load_tri(P.tris, two ? id1 : id0);
-                bool hit = tri_test(t0, id0, r, best_t, best_u, best_v, best_id);
-                if (!(ANY && hit) && two) hit = tri_test(t1, id1, r, best_t, best_u, best_v, best_id) || hit;
+                if (!two) id1 = id0;
+                const TriRec t0 = load_tri(tri_ptr(P.tris, in_block ? id0 : id0 * (kTriStride * 2u)));
+                const TriRec t1 = load_tri(tri_ptr(P.tris, in_block ? id1 : id1 * (kTriStride * 2u)));
+                bool hit = tri_test(t0, t0.tag, r, best_t, best_u, best_v, best_id);
+                if (!(ANY && hit) && two) hit = tri_test(t1, t1.tag, r, best_t, best_u, best_v, best_id) || hit;
                 any_done = ANY && hit;
                 leaf_i += 2;
             }
@@ -745,6 +771,9 @@ struct Options {
                               // cost more than the 1.7 ms the regrouped traversal saves
     int sort_bits = 6;        // cells per axis = 2^sort_bits (4..6)
     int treelet_levels = 3;   // read at gigl_scene_create: levels of child pairs per cache-line treelet (1..5)
+    int leaf_blocks = -1;     // read at gigl_scene_create (triple layout): leaves with at least this many prims read
+                              // a private block of triangle copies (kd_layout.h); 0 never; -1 the engine's choice:
+                              // 2 when tree and triangle table exceed the 256 MB Infinity Cache anyway, else 0
     int build_threads = 0;    // read at gigl_scene_create: host threads of the tree build (0: min(16, cores)); the
                               // tree does not depend on it
     int layout = 2;           // read at gigl_scene_create (kd_layout.h): 0 level treelets + separate id lists,
@@ -872,6 +901,7 @@ int launch_trace(const gigl_scene* s, TraceParams& P, hipStream_t st, const ExtW
     P.root_rec = s->root_rec;
     P.leaf_ids = s->d_leaf_ids ? s->d_leaf_ids : reinterpret_cast<const unsigned*>(s->d_nodes);  // clustered: lists in the node buffer
     P.tris = s->d_tris;
+    P.blocks_off8 = s->blocks_off8;
     P.box = s->box;
     // any-hit output: lane refill + atomicOr unless the caller asks for the group mode (a wave owns 64
     // consecutive rays and stores one word); with the current kernels the refill mode wins on shallow
@@ -982,6 +1012,7 @@ int gd::scene_clone_to_device(const gigl_scene* src, int device, gigl_scene** ou
     s->root = src->root; s->root_rec = src->root_rec; s->triples = src->triples; s->layout = src->layout;
     s->box = src->box; s->stats = src->stats;
     s->nb_nodes = src->nb_nodes; s->nb_leaf = src->nb_leaf; s->nb_tris = src->nb_tris;
+    s->blocks_off8 = src->blocks_off8;
     DeviceGuard g(device);
     auto cleanup = [&]() {
         if (s->d_nodes) (void)hipFree(s->d_nodes);
@@ -1030,15 +1061,16 @@ int gigl_device_count(int* count) {
 
 int gigl_debug_check_layout(const gigl_scene* s, int layout, int treelet_levels, uint64_t* bytes_out) {
     if (!s) return fail(GIGL_ERR_INVALID, "scene is NULL");
-    if (layout < 0 || layout > 2 || treelet_levels < 1 || treelet_levels > 5) return fail(GIGL_ERR_INVALID, "bad layout");
+    if (layout < 0 || layout > 3 || treelet_levels < 1 || treelet_levels > 5) return fail(GIGL_ERR_INVALID, "bad layout");
     gigl::DeviceTree dt;
-    if (layout == 2) {
+    if (layout == 3) dt.leaf_block_min = 2;   // layout 2 with leaf triangle blocks
+    if (layout >= 2) {
         if (!gigl::layout_triples(s->tree, dt)) return fail(GIGL_ERR_TOO_LARGE, "tree exceeds the triple-record encoding");
     } else if (layout == 1) gigl::layout_clustered(s->tree, dt);
     else gigl::layout_levels(s->tree, treelet_levels, dt);
     const char* what = nullptr;
     if (!gigl::layout_verify(s->tree, dt, &what)) return fail(GIGL_ERR_BUILD, std::string("device layout differs from the host tree: ") + (what ? what : "?"));
-    if (bytes_out) *bytes_out = dt.slots.size() * 8 + (dt.ids_inline ? 0 : dt.ids.size() * 4);
+    if (bytes_out) *bytes_out = dt.slots.size() * 8 + (dt.ids_inline ? 0 : dt.ids.size() * 4) + dt.block_ids.size() / 3 * 128;
     return GIGL_OK;
 }
 
@@ -1086,6 +1118,9 @@ int gigl_set_option(const char* name, int value) {
     } else if (k == "guided") {
         if (value < 0 || value > 64) return fail(GIGL_ERR_INVALID, "guided must be in 0..64");
         g_opt.guided = value;
+    } else if (k == "leaf_blocks") {
+        if (value < -1 || value == 1 || value > 64) return fail(GIGL_ERR_INVALID, "leaf_blocks must be -1, 0 or 2..64");
+        g_opt.leaf_blocks = value;
     } else if (k == "build_threads") {
         if (value < 0 || value > 256) return fail(GIGL_ERR_INVALID, "build_threads must be in 0..256");
         g_opt.build_threads = value;
@@ -1112,12 +1147,13 @@ int gigl_scene_create(const float* verts, uint32_t n_verts, const uint32_t* tris
         if (device < 0 || device >= n_dev) return fail(GIGL_ERR_INVALID, "device index out of range");
     }
 
-    int treelet_levels, layout, build_threads;
+    int treelet_levels, layout, build_threads, leaf_blocks;
     {
         std::lock_guard<std::mutex> lk(g_opt_mu);
         treelet_levels = g_opt.treelet_levels;
         layout = g_opt.layout;
         build_threads = g_opt.build_threads;
+        leaf_blocks = g_opt.leaf_blocks;
     }
     gigl_scene* s = new gigl_scene();
     s->device = device;
@@ -1160,8 +1196,11 @@ int gigl_scene_create(const float* verts, uint32_t n_verts, const uint32_t* tris
         r[0] = p0[0]; r[1] = p0[1]; r[2] = p0[2];
         r[3] = p1[0] - p0[0]; r[4] = p1[1] - p0[1]; r[5] = p1[2] - p0[2];
         r[6] = p2[0] - p0[0]; r[7] = p2[1] - p0[1]; r[8] = p2[2] - p0[2];
+        // word 9: the triangle's id, as in a leaf block's record (the kernel takes the id of a tested triangle
+        // from the record in both); word 10: material id (shading stage)
         uint32_t mat = tris[4 * (size_t)i + 3];
-        memcpy(&r[9], &mat, 4);
+        memcpy(&r[9], &i, 4);
+        memcpy(&r[10], &mat, 4);
     }
     DeviceGuard g(device);
     if (!g.ok) { delete s; return fail(GIGL_ERR_NO_DEVICE, "hipSetDevice failed"); }
@@ -1171,8 +1210,15 @@ int gigl_scene_create(const float* verts, uint32_t n_verts, const uint32_t* tris
     s->n_cus = prop.multiProcessorCount;
     // ---- device tree: same topology, re-addressed for the kernels (kd_layout.h) ----
     gigl::DeviceTree dtree;
-    if (layout == 2 && !gigl::layout_triples(s->tree, dtree)) layout = 1;   // beyond the record encoding: fall back
-    if (layout == 1) { dtree = gigl::DeviceTree(); gigl::layout_clustered(s->tree, dtree); }
+    if (layout == 2) {
+        // Leaf triangle blocks multiply the triangle bytes (a triangle is copied into every leaf that lists
+        // it): worth it only when the structure is served from HBM anyway.  Below the Infinity Cache's size
+        // the shared 64-byte table stays on-die and wins (kernels).
+        const size_t plain_bytes = s->tree.nodes.size() * 6 + (size_t)n_tris * 4 * kTriStride * 4;
+        dtree.leaf_block_min = leaf_blocks < 0 ? (plain_bytes > (size_t)200 << 20 ? 2u : 0u) : (uint32_t)leaf_blocks;
+        if (!gigl::layout_triples(s->tree, dtree)) { layout = 1; dtree = gigl::DeviceTree(); }   // beyond the record encoding: fall back
+    }
+    if (layout == 1) gigl::layout_clustered(s->tree, dtree);
     else if (layout == 0) gigl::layout_levels(s->tree, treelet_levels, dtree);
     s->triples = dtree.triples;
     s->layout = layout;
@@ -1185,7 +1231,13 @@ int gigl_scene_create(const float* verts, uint32_t n_verts, const uint32_t* tris
     }
     const size_t nb_nodes = std::max<size_t>(dn.size(), 2) * sizeof(uint2);
     const size_t nb_leaf = ids_inline ? 0 : std::max<size_t>(dtree.ids.size() + 2, 2) * 4;
-    const size_t nb_tris = std::max<size_t>(rec.size(), 16) * 4;
+    // the triangle table, then (triple layout with leaf triangle blocks) the blocks' 128-byte lines, in one
+    // allocation: the kernel names a record in either by one 32-bit offset
+    const size_t nb_table = (std::max<size_t>(rec.size(), 16) * 4 + 127) & ~(size_t)127;
+    const size_t n_block_lines = dtree.block_ids.size() / 3;
+    const size_t nb_blocks = n_block_lines ? n_block_lines * 128 + 128 : 0;   // a line of slack behind the last record
+    const size_t nb_tris = nb_table + nb_blocks;
+    if (nb_tris >= ((size_t)1 << 35)) { delete s; return fail(GIGL_ERR_TOO_LARGE, "triangle table and leaf blocks exceed 32 GB"); }
     auto cleanup = [&]() {
         if (s->d_nodes) (void)hipFree(s->d_nodes);
         if (s->d_leaf_ids) (void)hipFree(s->d_leaf_ids);
@@ -1213,6 +1265,28 @@ int gigl_scene_create(const float* verts, uint32_t n_verts, const uint32_t* tris
     s->root = make_uint2(dn[0].w0, dn[0].w1);
     s->root_rec = make_uint4(dn[0].w0, dn[0].w1, dn[1].w0, dn[1].w1);
     if (!rec.empty()) CREATE_TRY(hipMemcpy(s->d_tris, rec.data(), rec.size() * 4, hipMemcpyHostToDevice));
+    if (!dtree.block_ids.empty()) {
+        // leaf triangle blocks: 128-byte lines of three 40-byte records (p0, e0, e1, id), filled from the
+        // table records above and uploaded in slabs so the staging copy stays small
+        const size_t n_lines = n_block_lines;
+        char* const d_blocks = reinterpret_cast<char*>(s->d_tris) + nb_table;
+        s->blocks_off8 = (unsigned)(nb_table / 8);
+        const size_t slab_lines = (size_t)1 << 20;
+        std::vector<uint32_t> slab(std::min(n_lines, slab_lines) * 32);
+        for (size_t l0 = 0; l0 < n_lines; l0 += slab_lines) {
+            const size_t m = std::min(slab_lines, n_lines - l0);
+            std::memset(slab.data(), 0, m * 128);
+            for (size_t l = 0; l < m; ++l)
+                for (int k = 0; k < 3; ++k) {
+                    const uint32_t id = dtree.block_ids[(l0 + l) * 3 + k];
+                    if (id == gigl::kLeafBlockPad) continue;
+                    uint32_t* d = &slab[l * 32 + (size_t)k * 10];
+                    std::memcpy(d, &rec[(size_t)id * 4 * kTriStride], 36);
+                    d[9] = id;
+                }
+            CREATE_TRY(hipMemcpy(d_blocks + l0 * 128, slab.data(), m * 128, hipMemcpyHostToDevice));
+        }
+    }
 #undef CREATE_TRY
     s->box = BoxF{s->tree.box_min[0], s->tree.box_min[1], s->tree.box_min[2],
                   s->tree.box_max[0], s->tree.box_max[1], s->tree.box_max[2]};
@@ -1393,6 +1467,7 @@ int gigl_trace_one(const gigl_scene* s, const float o[3], const float d[3], floa
     P.recs = reinterpret_cast<const uint4*>(s->d_nodes); P.root_rec = s->root_rec;
     P.leaf_ids = s->d_leaf_ids ? s->d_leaf_ids : reinterpret_cast<const unsigned*>(s->d_nodes);
     P.tris = s->d_tris;
+    P.blocks_off8 = s->blocks_off8;
     P.box = s->box;
     P.refill_thresh = 1; P.chunk = 64; P.t_exit = 1;
     opt.guided = 0; opt.stats = 0;

@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(256) shade_surface_kernel(FogParams F, ShadePa
             const float4 tc = S.tris[kTriStride * (size_t)h.x + 2];
             N = norm3(cross3(f3(ta.w, tb.x, tb.y), f3(tb.z, tb.w, tc.x)));
             if (dot3(d, N) > 0.0f) N = -N;
-            const float* m = S.materials + 12 * (size_t)__float_as_uint(tc.y);
+            const float* m = S.materials + 12 * (size_t)__float_as_uint(tc.z);   // word 10 of the record: material id
             k_d = ld3(m); k_s = ld3(m + 4); n_s = m[7];
             O = -ray_d;
         }

@@ -276,6 +276,8 @@ bool layout_triples(const KdTreeHost& T, DeviceTree& dt) {
     dt.triples = true;
     dt.slots.clear();
     dt.ids.clear();
+    dt.block_ids.clear();
+    const uint32_t block_min = dt.leaf_block_min;
     const std::vector<KdNode>& H = T.nodes;
     if (dt.slot_of_host) dt.slot_of_host->assign(H.size(), 0u);
     if (dt.list_dw_of_host) dt.list_dw_of_host->assign(H.size(), ~0u);
@@ -311,12 +313,20 @@ bool layout_triples(const KdTreeHost& T, DeviceTree& dt) {
         for (uint32_t i = 0; i < n; ++i) W[4 * u + i] = id_of(k, i);
         for (uint32_t i = n; i < 4 * ids_units(n); ++i) W[4 * u + i] = 0u;
     };
+    auto in_block = [&](uint32_t k) { return block_min > 0u && n_of(k) >= block_min; };
     auto write_leaf_record = [&](uint32_t u, uint32_t k) {
         const uint32_t n = n_of(k);
-        if (n >= (1u << 30)) ok = false;
+        if (n >= (1u << 29)) ok = false;
         W[4 * u] = W[4 * u + 1] = W[4 * u + 2] = 0u;
         W[4 * u + 3] = 3u | (n << 2);
-        if (n <= 3u) {
+        if (in_block(k)) {   // the leaf's triangles, copied in list order into lines of their own
+            const size_t first_line = dt.block_ids.size() / 3u;
+            if (first_line > 0xFFFFFFFFull) ok = false;
+            W[4 * u] = (uint32_t)first_line;
+            W[4 * u + 3] |= kLeafBlockFlag;
+            for (uint32_t i = 0; i < n; ++i) dt.block_ids.push_back(id_of(k, i));
+            while (dt.block_ids.size() % 3u) dt.block_ids.push_back(kLeafBlockPad);
+        } else if (n <= 3u) {
             for (uint32_t i = 0; i < n; ++i) W[4 * u + i] = id_of(k, i);
         } else {
             const uint32_t a = alloc_aux(ids_units(n));
@@ -362,12 +372,13 @@ bool layout_triples(const KdTreeHost& T, DeviceTree& dt) {
     if (is_leaf(H[0])) { place_record(0, 0); return finish(); }
 
     const uint32_t n_nodes = (uint32_t)H.size();
+    auto arr_units = [&](uint32_t k) { return n_of(k) > 3u && !in_block(k) ? ids_units(n_of(k)) : 0u; };
     auto aux_of = [&](uint32_t g) -> uint32_t {   // units a record of node g wants beside it
-        if (is_leaf(H[g])) return n_of(g) > 3u ? ids_units(n_of(g)) : 0u;
+        if (is_leaf(H[g])) return arr_units(g);
         uint32_t a = 0;
         const uint32_t kids[2] = {g + 1u, H[g].w1 >> 3};
         for (uint32_t c : kids)
-            if (is_leaf(H[c]) && n_of(c) >= 2u) a += 1u + (n_of(c) > 3u ? ids_units(n_of(c)) : 0u);
+            if (is_leaf(H[c]) && n_of(c) >= 2u) a += 1u + arr_units(c);
         return a;
     };
     auto block_of = [&](uint32_t k, uint32_t g[4]) -> uint32_t {   // the grandchildren of interior node k
@@ -481,6 +492,14 @@ bool verify_triples(const KdTreeHost& T, const DeviceTree& D, const char** what)
     auto leaf_record_ok = [&](uint32_t u, uint32_t k) -> bool {
         if (u >= n_units) return false;
         const uint32_t n = n_of(k);
+        if (D.leaf_block_min > 0u && n >= D.leaf_block_min) {
+            if (W[4 * u + 3] != (3u | (n << 2) | kLeafBlockFlag)) return false;
+            const size_t first = (size_t)W[4 * u] * 3u;
+            if (first + n > D.block_ids.size()) return false;
+            for (uint32_t i = 0; i < n; ++i) if (D.block_ids[first + i] != id_of(k, i)) return false;
+            for (size_t i = first + n; i % 3u; ++i) if (D.block_ids[i] != kLeafBlockPad) return false;
+            return true;
+        }
         if (W[4 * u + 3] != (3u | (n << 2))) return false;
         if (n <= 3u) {
             for (uint32_t i = 0; i < n; ++i) if (W[4 * u + i] != id_of(k, i)) return false;

@@ -34,8 +34,14 @@ constexpr uint32_t kDevLeafBit = 0x80000000u, kDevLeafPayload = 0x1FFFFFFFu;
 //   leaf record (a leaf at an even depth, or the list of a child-position leaf):
 //     w = 3 | n << 2;  n <= 3: x, y, z = ids;  n > 3: x = unit index of the id array (dwords,
 //     padded to an even count, read 8 bytes at a time)
+//   leaf record with a triangle block (DeviceTree::leaf_block_min > 0 and n >= it):
+//     w = 3 | n << 2 | 1 << 31;  x = index of the first 128-byte line of the leaf's private block of
+//     triangle copies in a buffer of its own (three 40-byte records per line: p0, e0, e1, id), which
+//     the kernel reads in order instead of an id list plus one scattered 64-byte record per id.
+//     DeviceTree::block_ids lists the ids, three per line, padded with 0xFFFFFFFF.
 // One 16-byte load serves two levels of the descent.
 constexpr uint32_t kTriplePtrBits = 26;
+constexpr uint32_t kLeafBlockFlag = 0x80000000u, kLeafBlockPad = 0xFFFFFFFFu;
 
 struct DeviceTree {
     std::vector<KdNode> slots;          // 8-byte slots: nodes (and, clustered layout, inline id lists)
@@ -46,6 +52,10 @@ struct DeviceTree {
     // triple layout diagnostics: dword address of the extra record / id array a leaf reads (~0: none)
     std::vector<uint32_t>* list_dw_of_host = nullptr;
     bool triples = false;               // slots hold the triple layout (two slots per record)
+    // triple layout, in: leaves with at least this many prims get a private triangle block (0: none);
+    // out: the ids of the blocks' records, three per 128-byte line
+    uint32_t leaf_block_min = 0;
+    std::vector<uint32_t> block_ids;
 };
 
 // Level layout: treelets of `levels` breadth-first levels of child pairs that never straddle a

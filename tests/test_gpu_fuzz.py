@@ -76,4 +76,14 @@ def test_random_soup(seed, n_tris, scale, flavour, params):
     occ = ora.trace_any(ro, rd, n_threads=4)
     assert np.array_equal(gpu.trace(ro, rd, is_vis_ray=True), occ.astype(bool))
     gpu.close()
+    # the same scene with leaf triangle blocks (the default of scenes beyond the Infinity Cache's size)
+    try:
+        rt.set_option("leaf_blocks", 2)
+        gpu = rt.Scene(verts, tris, device=0, **params)
+        got = gpu.trace(ro, rd)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        assert np.array_equal(gpu.trace(ro, rd, is_vis_ray=True), occ.astype(bool))
+        gpu.close()
+    finally:
+        rt.set_option("leaf_blocks", -1)
     ora.close()

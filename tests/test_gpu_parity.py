@@ -197,6 +197,41 @@ def test_other_tree_shapes(cornell, layout, params):
         rt.set_option("layout", 2)
 
 
+@pytest.mark.parametrize("block_min", [2, 4])
+@pytest.mark.parametrize("params", [S.KD_PARAMS,
+                                    dict(inters_cost=10, trav_cost=1, max_depth=6, min_num_prims=2, empty_bonus=0.25),
+                                    dict(inters_cost=1, trav_cost=10, max_depth=14, min_num_prims=9, empty_bonus=0.0)])
+def test_leaf_triangle_blocks(cornell, cornell_cam, oracle_cornell, block_min, params):
+    """Triple records whose leaves read private blocks of triangle copies (three 40-byte records per
+    line, in list order) instead of id lists and the shared table - what scenes beyond the Infinity
+    Cache's size get by default.  Same tree, same triangles in the same order: records and bits are
+    the oracle's, on deep trees, on shallow trees with hundreds of prims per leaf, and on Cornell."""
+    V, T = synth.tessellate(cornell["verts"], cornell["tris"], 14)
+    ora = O.OracleScene(V, T, **params)
+    try:
+        rt.set_option("leaf_blocks", block_min)
+        g = rt.Scene(V, T, device=0, **params)
+        gc = rt.Scene(cornell["verts"], cornell["tris"], device=0, **S.KD_PARAMS)
+        assert g.check_layout(3) > g.check_layout(2)
+        ro, rd = synth.bounce_rays(V, T, 80_001, 0xB10C05)
+        want = ora.trace_closest(ro, rd, n_threads=4)
+        assert_hits_equal(g.trace(ro, rd), want)
+        for any_atomic in (0, 1):
+            rt.set_option("any_atomic", any_atomic)
+            assert np.array_equal(g.trace(ro, rd, is_vis_ray=True), ora.trace_any(ro, rd, n_threads=4))
+        po, pd = O.primary_rays(cornell_cam, 1024, 0, 1024 * 1024)
+        sel = slice(0, 1024 * 1024, 11)
+        assert_hits_equal(gc.trace(po[sel], pd[sel]), oracle_cornell.trace_closest(po[sel], pd[sel], n_threads=4))
+        hit, rec, nrm = gc.trace_one([278, 273, -800], [0, 0, 1])
+        w_hit, w_rec, w_nrm, _ = oracle_cornell.trace_one([278, 273, -800], [0, 0, 1])
+        assert hit == w_hit and rec["tri_id"] == w_rec["tri_id"] and np.array_equal(nrm.view(np.uint32), w_nrm.view(np.uint32))
+        g.close()
+        gc.close()
+    finally:
+        rt.set_option("leaf_blocks", -1)
+        rt.set_option("any_atomic", -1)
+
+
 def test_edge_cases(gpu_cornell, oracle_cornell):
     # empty batch
     assert len(gpu_cornell.trace(np.zeros((0, 4), np.float32), np.zeros((0, 4), np.float32))) == 0

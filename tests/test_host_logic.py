@@ -71,7 +71,8 @@ def test_builder_is_independent_of_thread_count(cornell):
 
 
 def test_device_layouts_keep_the_tree(cornell):
-    # re-addressing for the device (level treelets, clustered lines with inline id lists) changes
+    # re-addressing for the device (level treelets, clustered lines with inline id lists, triple records,
+    # triple records with leaf triangle blocks = check_layout(3)) changes
     # addresses only: every split, axis, child order and leaf list is checked against the host tree
     scenes = [(cornell["verts"], cornell["tris"])]
     scenes += [synth.tessellate(cornell["verts"], cornell["tris"], k) for k in (3, 12, 40)]
@@ -81,7 +82,7 @@ def test_device_layouts_keep_the_tree(cornell):
     for V, T in scenes:
         for params in (S.KD_PARAMS, dict(inters_cost=10, trav_cost=1, max_depth=4, min_num_prims=2, empty_bonus=0.25)):
             ps = rt.Scene(V, T, device=-1, **params)
-            sizes = [ps.check_layout(0, lv) for lv in (1, 2, 3, 4, 5)] + [ps.check_layout(1), ps.check_layout(2)]
+            sizes = [ps.check_layout(0, lv) for lv in (1, 2, 3, 4, 5)] + [ps.check_layout(1), ps.check_layout(2), ps.check_layout(3)]
             assert all(b >= 16 for b in sizes)
             ps.close()
 

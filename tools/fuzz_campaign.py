@@ -32,9 +32,10 @@ for seed in range(first, first + n_scenes):
     ro, rd = rays_for(rng, verts, tris, 20001, scale)
     want = ora.trace_closest(ro, rd, n_threads=8)
     occ = ora.trace_any(ro, rd, n_threads=8).astype(bool)
-    for layout in (0, 1, 2):
+    for layout in (0, 1, 2, 3):   # 3: triple records with leaf triangle blocks
         for stack_lds in (8, 16):
-            rt.set_option("layout", layout)
+            rt.set_option("layout", min(layout, 2))
+            rt.set_option("leaf_blocks", 2 if layout == 3 else 0)
             rt.set_option("stack_lds", stack_lds)
             gpu = rt.Scene(verts, tris, device=0, **params)
             got = gpu.trace(ro, rd)
@@ -54,7 +55,8 @@ for seed in range(first, first + n_scenes):
     if seed % 10 == 9:
         print("seed %d done, %.0f s, mismatching configurations so far: %d" % (seed, time.time() - t0, bad), flush=True)
 rt.set_option("layout", 2)
+rt.set_option("leaf_blocks", -1)
 rt.set_option("stack_lds", 8)
-print("campaign: %d scenes x 3 layouts x 2 stack depths x (closest + 2 any-hit modes): %d mismatching configurations"
+print("campaign: %d scenes x 4 layouts x 2 stack depths x (closest + 2 any-hit modes): %d mismatching configurations"
       % (n_scenes, bad))
 sys.exit(1 if bad else 0)

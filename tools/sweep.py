@@ -48,12 +48,17 @@ def main():
         rt.set_option("treelet_levels", a.treelet)
     scenes = {}
 
-    def scene_for(layout):   # layout=L: a scene created under that device layout (kd_layout.h)
-        if layout not in scenes:
+    def scene_for(layout, leaf_blocks=-1):   # layout=L, leaf_blocks=B: a scene created under those options (kd_layout.h)
+        key = (layout, leaf_blocks)
+        if key not in scenes:
             rt.set_option("layout", layout)
-            scenes[layout] = rt.Scene(V, T, device=0, **S.KD_PARAMS)
-            print("layout", layout, "device bytes", scenes[layout].stats().device_bytes, flush=True)
-        return scenes[layout]
+            try:
+                rt.set_option("leaf_blocks", leaf_blocks)
+            except rt.GiglError:
+                pass   # an older library under GIGL_RT_LIB
+            scenes[key] = rt.Scene(V, T, device=0, **S.KD_PARAMS)
+            print("layout", layout, "leaf_blocks", leaf_blocks, "device bytes", scenes[key].stats().device_bytes, flush=True)
+        return scenes[key]
     scene = scene_for(2)
     n = 1 << a.rays_log2
     ro, rd = synth.bounce_rays(V, T, n, synth.RAY_SEED_16M)
@@ -75,7 +80,7 @@ def main():
     for r in range(a.rounds + 1):
         for v in a.variants:
             opts = dict(defaults)
-            pseudo = {"sorted": 0, "any": 0, "stats": 0, "layout": 2}
+            pseudo = {"sorted": 0, "any": 0, "stats": 0, "layout": 2, "leaf_blocks": -1}
             for kv in v.split(","):
                 if not kv or kv == "base":
                     continue
@@ -89,7 +94,7 @@ def main():
                         raise
             rt.set_option("stats", pseudo["stats"])
             o, d = presorted(pseudo["sorted"]) if pseudo["sorted"] else (d_o, d_d)
-            scene = scene_for(pseudo["layout"])
+            scene = scene_for(pseudo["layout"], pseudo["leaf_blocks"])
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             # the first of the two launches is untimed: a variant with a different grid makes the
             # stream-ordered pool allocate a new workspace block, which costs ~0.5 ms once
