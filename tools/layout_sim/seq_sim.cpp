@@ -312,7 +312,8 @@ static void walk_host(const Scene& S, const gigl::KdTreeHost& T, const Abstract&
 // plus the units of the leaf records / id arrays of its leaf children, which go with it.  No constraint on
 // where sibling records go.  min_fill: a cluster root starts a new line unless its whole subtree fits in
 // what is left of the current one.
-static Abstract cluster_free(const gigl::KdTreeHost& T, size_t* bytes_out, uint32_t rec_dw = 4, bool pairs_adjacent = false) {
+static Abstract cluster_free(const gigl::KdTreeHost& T, size_t* bytes_out, uint32_t rec_dw = 4, bool pairs_adjacent = false,
+                             uint32_t line_dw = 32, bool own_line = false) {
     const std::vector<KdNode>& H = T.nodes;
     const size_t n = H.size();
     Abstract A;
@@ -367,7 +368,7 @@ static Abstract cluster_free(const gigl::KdTreeHost& T, size_t* bytes_out, uint3
         const float split = asf(H[parent].w0);
         if (j == 0) b[3 + axis] = split; else b[axis] = split;
     };
-    constexpr uint32_t kLineU = 32;
+    const uint32_t kLineU = line_dw;   // usable dwords per 128-byte line (a header takes the rest)
     if (pairs_adjacent)
         for (uint32_t k = 0; k < n; ++k)
             if (!is_leaf(k)) { /* children of k: k+1 and above; if they are record roots (odd-depth parent) pair them */ }
@@ -410,7 +411,7 @@ static Abstract cluster_free(const gigl::KdTreeHost& T, size_t* bytes_out, uint3
         roots.pop_back();
         const uint32_t free_u = kLineU - used;
         const uint32_t need = sub[r.k] + (partner[r.k] != ~0u ? sub[partner[r.k]] : 0u);
-        if (!(need <= free_u)) { line = n_lines++; used = 0; }
+        if (own_line || !(need <= free_u)) { line = n_lines++; used = 0; }   // own_line: every cluster root starts a line
         heap.clear();
         heap.push_back(r);
         std::vector<Cand> deferred;
@@ -602,14 +603,15 @@ int main(int argc, char** argv) {
                 show(nm, price(seqs, hot_frac), D2.slots.size() * 8 + next);
             }
         }
-        struct V { const char* name; uint32_t dw; bool adj; bool bv; };
-        const V vars[] = {{"free-form, 16 B records (bound)", 4, false, false}, {"free-form, 20 B records", 5, false, false},
-                          {"free-form, 24 B records", 6, false, false}, {"pairs adjacent, 16 B (bound)", 4, true, false},
-                          {"pairs adjacent, 20 B", 5, true, false}, {"pairs adjacent, 24 B", 6, true, false},
-                          {"pairs adjacent, 24 B, far by value", 6, true, true}};
+        struct V { const char* name; uint32_t dw; bool adj; bool bv; uint32_t line_dw; bool own; };
+        const V vars[] = {{"free-form, 16 B records (bound)", 4, false, false, 32, false},
+                          {"free-form 16 B, 7 units + header, root per line", 4, false, false, 28, true},
+                          {"free-form 16 B, 7 units + header, shared lines", 4, false, false, 28, false},
+                          {"free-form, 20 B records", 5, false, false, 32, false},
+                          {"pairs adjacent, 16 B (bound)", 4, true, false, 32, false}};
         for (const V& v : vars) {
             size_t bytes = 0;
-            const Abstract A = cluster_free(T, &bytes, v.dw, v.adj);
+            const Abstract A = cluster_free(T, &bytes, v.dw, v.adj, v.line_dw, v.own);
             reset();
             for (size_t i = 0; i < rays.size(); ++i) walk_host(S, T, A, rays[i], v.bv, seqs[i]);
             show(v.name, price(seqs, hot_frac), bytes);
