@@ -16,6 +16,9 @@
   generator) + one any-hit shadow ray per (hit pixel, VPL) for the 150 golden VPLs (~152 M pairs).
 --config transmittance    BASELINE.json configs[4]: calcTransm (8-interval ray march through the 64^3
   density volume) of the same ~152 M shadow segments.
+--config vpl              BASELINE.json configs[0]: Cornell box, generation of the 150-VPL set
+  (rt::PhotonTracer::trace) as ray batches (gigl_photon_trace_batch, substream mode), beside the oracle's
+  serial walk in the same mode; --vpls N changes the set size.
 
 Prints ONE JSON line on rank 0.
 """
@@ -41,7 +44,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="bounce", choices=["bounce", "cornell_shadow", "transmittance"])
+    ap.add_argument("--config", default="bounce", choices=["bounce", "cornell_shadow", "transmittance", "vpl"])
+    ap.add_argument("--vpls", type=int, default=None, help="--config vpl: VPLs per set (default MAX_N_VPLS = 150)")
     ap.add_argument("--tess", type=int, default=None,
                     help="k of scene S(k); default 158 (998,560 triangles) at N = 1, 500 (10 M) at N > 1")
     ap.add_argument("--rays-log2", type=int, default=None, help="rays per GPU = 2^this (weak scaling)")
@@ -128,7 +132,7 @@ def main():
     if args.config != "bounce":
         if world > 1:
             raise SystemExit("--config %s is a single-GPU configuration" % args.config)
-        out = cornell_config(args, torch, rt, S, device)
+        out = (vpl_config if args.config == "vpl" else cornell_config)(args, torch, rt, S, device)
         print(json.dumps(out), flush=True)
         return
 
@@ -505,6 +509,63 @@ def cornell_config(args, torch, rt, S, device):
             "transmittance_all_pairs_ms": round(timeit(lambda: cs.shadow_batch_device(*args_, None, fog=fog, transm_ptr=tr2.data_ptr(), stream=sh)), 3),
             "fused_bits_and_visible_transmittance_ms": round(timeit(lambda: cs.shadow_batch_fused_device(*args_, bits.data_ptr(), fog, tr2.data_ptr(), stream=sh)), 3),
             "occluded_fraction": round(float(rt.unpack_bits(bits.cpu().numpy().view(np.uint64), npair).sum()) / max(nhit * nl, 1), 4)}
+    fog.close()
+    cs.close()
+    return out
+
+
+def vpl_config(args, torch, rt, S, device):
+    """configs[0]: VPL generation for the Cornell box's primary light as ray batches.  A step is one whole set
+    (paths walked in blocks: one closest-hit batch per bounce, one lane per path, then the ordered gather)."""
+    from oracle import oracle_py as O
+    t0 = time.time()
+    ci = cornell_inputs(torch, rt, S, device)
+    cs, fog, mats = ci["scene"], ci["fog"], ci["mats"]
+    n_vpls = args.vpls or S.MAX_N_VPLS
+    call = lambda seed: cs.photon_trace_batch(mats, fog, S.ABS_K, S.SCA_K, S.MAJ_EXT_K, 1, S.PRIM_PL_POS,
+                                              S.PRIM_PL_INTENS, [0, -1, 0], n_vpls, seed)
+    setup_s = time.time() - t0
+    for i in range(args.warmup):
+        call(1000 + i)
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    paths = 0
+    for i in range(args.steps):   # every step a fresh seed, as every frame of the reference draws fresh numbers
+        n, got, n_paths = call(1 + i)
+        paths += n_paths
+    elapsed = time.perf_counter() - t_start   # the call returns the records to the host: it synchronises itself
+    ms_per_step = elapsed * 1e3 / args.steps
+    hinfo = host_info(O)
+    cpu = parity = None
+    if not args.no_cpu_baseline:
+        ora = O.OracleScene(ci["verts"], ci["tris"], **S.KD_PARAMS)
+        fog_o = O.Fog(ci["dens"], ci["box"], fog.ext_k)
+        walk = lambda seed: O.photon_trace_substreams(ora, mats, fog_o, S.ABS_K, S.SCA_K, S.MAJ_EXT_K, 1, S.PRIM_PL_POS,
+                                                      S.PRIM_PL_INTENS, [0, -1, 0], n_vpls, seed)
+        reps = max(args.steps, 20 if n_vpls <= 1000 else 3)
+        t1 = time.perf_counter()
+        for i in range(reps):
+            wn, want, want_paths, _ = walk(1 + (i % args.steps))
+        cpu_s = (time.perf_counter() - t1) / reps
+        wn, want, want_paths, _ = walk(args.steps)
+        want = np.frombuffer(want.tobytes(), np.uint32).reshape(-1, 24)
+        parity = {"vpls_checked": int(n), "record_mismatches": int((got != want).any(1).sum()),
+                  "n_paths": [int(n_paths), int(want_paths)], "mode": "substreams (parity unpinned against the reference)"}
+        cpu = {"value": round(n_vpls / cpu_s / 1e3, 3), "unit": "kVPLs/s", "cores": 1, "kind": "port", "threads_used": 1,
+               "sample": "the same sets (same seeds), serial oracle walk ora_photon_trace_substreams, %.3f ms per set" % (cpu_s * 1e3),
+               "omp_get_max_threads": hinfo.get("omp_get_max_threads"), "cpu_model": hinfo["cpu_model"]}
+    out = {"metric": "kVPLs/s (VPL generation as ray batches)", "value": round(n_vpls * args.steps / elapsed / 1e3, 3),
+           "unit": "kVPLs/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "Cornell box (40 triangles), %d-VPL set from the primary light, fog on: %.0f paths per "
+                                  "set, 3 bounces, one closest-hit batch per bounce" % (n_vpls, paths / args.steps),
+                      "baseline_config": "configs[0]", "vpls": n_vpls, "paths_per_set": paths / args.steps,
+                      "device_layout": cs.layout(), "setup_s": round(setup_s, 1), "commit": git_head()},
+           "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                        "kernel": "photon_start/bounce kernels + trace_kernel per bounce",
+                        "note": "launch-latency bound at this size: a set is ~12 launches over a few hundred to a few "
+                                "thousand paths and one 16-byte read-back per block of paths; no bandwidth figure applies"},
+           "cpu_baseline": cpu, "parity": parity, "host": hinfo}
     fog.close()
     cs.close()
     return out

@@ -306,6 +306,9 @@ namespace gd {
 // records are copied device to device, the host tree's vectors are not duplicated.  Defined in
 // gigl_rt.hip, used by the multi-device entry points (gigl_multi.hip).
 int scene_clone_to_device(const gigl_scene* src, int device, gigl_scene** out);
+// gigl_rt.hip: closest-hit batch with per-ray final ranges and hit triangle records (gigl_photon.hip)
+int trace_closest_ranges(const gigl_scene* s, const float4* o_tmin, const float4* d_tmax, unsigned n, uint4* hits,
+                         float2* ranges, float4* hit_tri, hipStream_t st);
 
 struct DeviceGuard {
     int prev = -1;

@@ -1,0 +1,465 @@
+// gigl_photon.hip — rt::PhotonTracer::trace (Source/RT/PhotonTracer.cpp:78-188) as ray batches.
+//
+// The reference walks one path at a time and draws every random number from one global generator
+// (Source/Common/Random.cpp:11-18), so path p's numbers depend on how many paths 0..p-1 consumed.  The
+// batched walk gives every path a random-number substream of its own (the build's definition, stated in
+// include/gigl_rt.h and mirrored by the oracle's ora_photon_trace_substreams), walks a block of paths
+// at once — one closest-hit batch per bounce through the same traversal kernel as every other query,
+// one lane per path for Woodcock tracking, Russian roulette, VPL records and the next ray — and then
+// keeps the VPLs of the first paths, in path order, up to max_vpl_count, exactly as the serial loop
+// would have: the path that supplies VPL number max_vpl_count is the last one counted (:115, :159,
+// :180), LightArray::normalizeIntensity (Source/VPL/LightArray.hpp:46-66) renumbers path ids and divides
+// by the number of paths.  The serial single-stream walk stays available to a C++ host through
+// gigl_trace_one (gigl_amd/host/gigl_host.hpp).
+//
+// cos, sin, log and pow are evaluated in double precision and rounded to float: the correctly rounded
+// float result, the same on host and device, which no float libm guarantees.  Everything else is the
+// float arithmetic of the reference in the reference's order (-ffp-contract=off).
+#include "gigl_internal.h"
+
+using namespace gd;
+
+namespace {
+
+// Source/Common/Constants.h
+constexpr float kTwoPi = 6.28318548f, kPi = 3.14159274f, kInvPi = 0.318309873f;
+constexpr float kSurvivalRR = 0.95f, kMaxFogHeight = 548.8f, kHgG = 0.25f;
+constexpr int kGiBounces = 3;
+
+__host__ __device__ inline unsigned long long splitmix64(unsigned long long z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// draw k of path p: the top 24 bits of splitmix64(key(p) + k * gamma), scaled to [0, 1)
+struct Draw {
+    unsigned long long key;
+    unsigned k;
+    __device__ float operator()() {
+        const unsigned long long z = splitmix64(key + (unsigned long long)k * 0x9E3779B97F4A7C15ull);
+        ++k;
+        return (float)(unsigned)(z >> 40) * 5.9604644775390625e-8f;
+    }
+};
+__device__ __forceinline__ unsigned long long path_key(unsigned long long seed, unsigned path) {
+    return splitmix64(seed ^ splitmix64((unsigned long long)path));
+}
+
+__device__ __forceinline__ float cr_cos(float x) { return (float)cos((double)x); }
+__device__ __forceinline__ float cr_sin(float x) { return (float)sin((double)x); }
+__device__ __forceinline__ float cr_log(float x) { return (float)log((double)x); }
+__device__ __forceinline__ float cr_pow(float x, float y) { return (float)pow((double)x, (double)y); }
+
+__device__ __forceinline__ F3 vec_sin_cos(float phi, float sin_the, float cos_the) {   // RTBase.h:44-50
+    return f3(sin_the * cr_cos(phi), sin_the * cr_sin(phi), cos_the);
+}
+struct M3 { F3 c0, c1, c2; };
+__device__ __forceinline__ F3 mul3(const M3& m, F3 v) {   // GLM type_mat3x3.inl:593-596
+    return f3((m.c0.x * v.x + m.c1.x * v.y) + m.c2.x * v.z, (m.c0.y * v.x + m.c1.y * v.y) + m.c2.y * v.z,
+              (m.c0.z * v.x + m.c1.z * v.y) + m.c2.z * v.z);
+}
+__device__ __forceinline__ M3 span_tangent_space(F3 normal) {   // RTBase.h:33-41
+    const F3 c1 = cross3(normal, f3(0.0f, 0.0f, 1.0f)), c2 = cross3(normal, f3(0.0f, 1.0f, 0.0f));
+    const F3 c3 = len3(c1) > len3(c2) ? c1 : c2;
+    const F3 tangent = norm3(-c3);
+    return M3{tangent, cross3(normal, tangent), normal};
+}
+
+struct PathState {
+    float ax, ay, az;     // attenuation
+    unsigned k;           // draws taken from the path's substream so far
+    unsigned alive;       // the path still has a ray in flight
+    unsigned n_vpl;       // VPL records written to the path's slots (at most kGiBounces)
+    unsigned pad0, pad1;
+};
+struct VplRec { unsigned w[24]; };   // 96 B, PointLight.h:66-77 (std140)
+
+struct WalkParams {
+    // per path of the block
+    PathState* state;
+    float4* o_tmin;
+    float4* d_tmax;
+    const uint4* hits;
+    const float2* ranges;
+    const float4* hit_tri;
+    VplRec* slots;            // kGiBounces per path
+    unsigned first, n;        // path ids [first, first + n)
+    unsigned long long seed;
+    // scene
+    const float* materials;   // 12 floats per material: k_d, -, k_s, n_s, k_e, -
+    unsigned n_mat;
+    FogParams fog;
+    BoxF fog_box;
+    int fog_on;
+    float abs_k, sca_k, maj_ext_k;
+    float src[3], src_int[3];
+    unsigned* error;          // set when a hit triangle names a material beyond n_mat
+};
+
+__device__ __forceinline__ void store_ray(const WalkParams& W, unsigned i, F3 o, F3 d) {
+    W.o_tmin[i] = make_float4(o.x, o.y, o.z, 0.0f);        // Ray ctor: valid range (0, FLT_MAX), RTBase.cpp:111-115
+    W.d_tmax[i] = make_float4(d.x, d.y, d.z, FLT_MAX);
+}
+// A path that has ended keeps a ray with an empty range, which leaves the traversal at the box test.
+__device__ __forceinline__ void retire(const WalkParams& W, unsigned i, PathState& st) {
+    st.alive = 0u;
+    W.o_tmin[i].w = FLT_MAX;
+    W.d_tmax[i].w = -FLT_MAX;
+}
+
+// PhotonTracer.cpp:84-93: the start of a path
+__global__ void __launch_bounds__(256) photon_start_kernel(const WalkParams W) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= W.n) return;
+    Draw draw{path_key(W.seed, W.first + i), 0u};
+    if (W.src[2] <= kMaxFogHeight) (void)draw();   // :86 — the draw is made, its result never reaches the path (:88-92)
+    const float u1 = draw(), u0 = draw();          // :90, arguments evaluated right to left
+    const float sin_the = sqrtf(1.0f - u1 * u1);
+    const F3 dir = vec_sin_cos(kTwoPi * u0, sin_the, u1);
+    const float pdf = 0.5f * kInvPi;
+    const float ia = 1.0f / pdf;
+    PathState st;
+    st.ax = ia; st.ay = ia; st.az = ia;
+    st.k = draw.k; st.alive = 1u; st.n_vpl = 0u; st.pad0 = st.pad1 = 0u;
+    W.state[i] = st;
+    store_ray(W, i, f3(W.src[0], W.src[1], W.src[2]), dir);
+}
+
+__device__ __forceinline__ float sample_density(const FogParams& F, F3 p) {   // DensityField.cpp:177-202, BBox.cpp:53-55
+    return fog_filter(F, (p.x - F.mnx) / (F.mxx - F.mnx), (p.y - F.mny) / (F.mxy - F.mny), (p.z - F.mnz) / (F.mxz - F.mnz));
+}
+
+// PhotonTracer.cpp:95-178: what happens to a path after scene.trace(ray), one lane per path
+__global__ void __launch_bounds__(256) photon_bounce_kernel(const WalkParams W, int last_bounce) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= W.n) return;
+    PathState st = W.state[i];
+    if (!st.alive) return;
+    Draw draw{path_key(W.seed, W.first + i), st.k};
+    const float4 o4 = W.o_tmin[i], d4 = W.d_tmax[i];
+    const F3 o = f3(o4.x, o4.y, o4.z), d = f3(d4.x, d4.y, d4.z);
+    const uint4 h = W.hits[i];
+    const bool hit = h.x != kMiss;
+    const float dist = __uint_as_float(h.y);   // FLT_MAX when nothing was hit (Intersection's initial distance)
+    const float2 rg = W.ranges[i];             // t_min, t_max as KdTree::intersect left them in the ray
+    RayReg r;
+    r.ox = o.x; r.oy = o.y; r.oz = o.z;
+    set_dir(r, d.x, d.y, d.z);
+    r.tmin = rg.x; r.tmax = rg.y;
+    const F3 src_int = f3(W.src_int[0], W.src_int[1], W.src_int[2]);
+    VplRec* const slots = W.slots + (size_t)i * kGiBounces;
+    bool go_on = false;      // the bounce ended in `continue` (a new ray was made)
+    bool surface = true;     // fall through to the surface event
+    F3 new_o = o, new_d = d;
+    float f_entr = FLT_MAX, f_exit = -FLT_MAX;
+    const bool fog_hit = W.fog_on ? box_intersect(W.fog_box, r, f_entr, f_exit) : false;   // Scene::traceFog, Scene.cpp:245-251
+    if (fog_hit) {
+        const float t_lo = gmax(f_entr, 0.0f), t_hi = gmin(f_exit, dist);   // :101-102
+        bool event = false;
+        float t_event = 0.0f;
+        if (0.0f != W.maj_ext_k) {   // calcEventDistWT, :62-76
+            float d_event = t_lo, p_event = 0.0f;
+            while (d_event < t_hi && p_event < draw()) {
+                const float dt = -cr_log(1.0f - draw()) / W.maj_ext_k;
+                d_event += dt;
+                const F3 s_pos = o + d_event * d;
+                const float ext_k = (W.abs_k + W.sca_k) * sample_density(W.fog, s_pos);   // FogVolume.cpp:32-36
+                p_event = ext_k / W.maj_ext_k;
+            }
+            event = d_event < t_hi;
+            t_event = d_event;
+        }
+        if (event) {
+            surface = false;
+            const F3 event_pt = o + t_event * d;
+            const float sk = W.sca_k * sample_density(W.fog, event_pt);   // FogVolume.cpp:38-41
+            const float sca_albedo = W.sca_k / (W.abs_k + W.sca_k);
+            if (draw() < sca_albedo) {
+                const F3 I = d;
+                const F3 vi = src_int * f3(st.ax, st.ay, st.az);
+                VplRec v;
+                for (int k = 0; k < 24; ++k) v.w[k] = 0u;   // PointLight.cpp:15-17
+                v.w[0] = __float_as_uint(event_pt.x); v.w[1] = __float_as_uint(event_pt.y); v.w[2] = __float_as_uint(event_pt.z);
+                v.w[3] = 1u;
+                v.w[4] = __float_as_uint(vi.x); v.w[5] = __float_as_uint(vi.y); v.w[6] = __float_as_uint(vi.z);
+                v.w[7] = __float_as_uint(sk);
+                v.w[8] = __float_as_uint(I.x); v.w[9] = __float_as_uint(I.y); v.w[10] = __float_as_uint(I.z);
+                v.w[11] = W.first + i;
+                slots[st.n_vpl++] = v;
+                // HGPhaseFunc::importanceSample, :49-58
+                const float hphi = kTwoPi * draw();
+                const float uu = draw();
+                const float nn = 1.0f - kHgG * kHgG;
+                const float dd = 1.0f - kHgG + 2.0f * kHgG * uu;
+                const float q = nn / dd;
+                const float cos_the = 0.5f / fabsf(kHgG) * (1.0f + kHgG * kHgG - q * q);
+                const float sin_t = sqrtf(1.0f - cos_the * cos_the);
+                const F3 O = mul3(span_tangent_space(I), vec_sin_cos(hphi, sin_t, cos_the));
+                st.ax = st.ax * 1.0f; st.ay = st.ay * 1.0f; st.az = st.az * 1.0f;   // throughput 1 (:57, :122)
+                new_o = event_pt; new_d = O;   // Ray{event_pt, O}
+                go_on = true;
+            }
+        }
+    }
+    if (surface && hit) {
+        const F3 hit_pt = o + dist * d;
+        const float4 ta = W.hit_tri[3 * (size_t)i], tb = W.hit_tri[3 * (size_t)i + 1], tc = W.hit_tri[3 * (size_t)i + 2];
+        // Scene::trace leaves normalize(cross(e0, e1)) in the ray (RTBase.cpp:170, Scene.cpp:238)
+        const F3 norm = norm3(cross3(f3(ta.w, tb.x, tb.y), f3(tb.z, tb.w, tc.x)));
+        const unsigned mat_id = __float_as_uint(tc.z);
+        if (mat_id >= W.n_mat) {
+            *W.error = 1u;
+        } else if (!(dot3(d, norm) >= 0.0f || hit_pt.z > kMaxFogHeight)) {   // :139
+            const float* mat = W.materials + 12 * (size_t)mat_id;
+            const F3 k_d = ld3(mat), k_s = ld3(mat + 4);
+            const float n_s = mat[7];
+            const bool emissive = mat[8] > 0.0f || mat[9] > 0.0f || mat[10] > 0.0f;
+            if (!emissive && draw() < kSurvivalRR) {
+                st.ax = st.ax / kSurvivalRR; st.ay = st.ay / kSurvivalRR; st.az = st.az / kSurvivalRR;
+                const F3 I = -d;
+                const F3 vi = src_int * f3(st.ax, st.ay, st.az);
+                const F3 lifted = hit_pt + 1E-4f * norm;   // PointLight.cpp:21
+                VplRec v;
+                for (int k = 0; k < 24; ++k) v.w[k] = 0u;
+                v.w[0] = __float_as_uint(lifted.x); v.w[1] = __float_as_uint(lifted.y); v.w[2] = __float_as_uint(lifted.z);
+                v.w[3] = 2u;
+                v.w[4] = __float_as_uint(vi.x); v.w[5] = __float_as_uint(vi.y); v.w[6] = __float_as_uint(vi.z);
+                v.w[8] = __float_as_uint(I.x); v.w[9] = __float_as_uint(I.y); v.w[10] = __float_as_uint(I.z);
+                v.w[11] = W.first + i;
+                v.w[12] = __float_as_uint(norm.x); v.w[13] = __float_as_uint(norm.y); v.w[14] = __float_as_uint(norm.z);
+                v.w[16] = __float_as_uint(k_d.x); v.w[17] = __float_as_uint(k_d.y); v.w[18] = __float_as_uint(k_d.z);
+                v.w[20] = __float_as_uint(k_s.x); v.w[21] = __float_as_uint(k_s.y); v.w[22] = __float_as_uint(k_s.z);
+                v.w[23] = __float_as_uint(n_s);
+                slots[st.n_vpl++] = v;
+                // PhongMaterial::importanceSampleBRDF, RTBase.cpp:70-109
+                const float bu1 = draw(), bu2 = draw();
+                const F3 lum = f3(0.2126f, 0.7152f, 0.0722f);
+                const float dw = dot3(k_d, lum), gw = dot3(k_s, lum);
+                const float sp_diffuse = dw / (dw + gw);
+                const float u_rand = draw();
+                F3 O, throughput;
+                if (u_rand < sp_diffuse) {
+                    const F3 micro_O = vec_sin_cos(kTwoPi * bu1, sqrtf(1.0f - bu2), sqrtf(bu2));   // RTBase.cpp:27-36
+                    O = mul3(span_tangent_space(norm), micro_O);
+                    const float den = micro_O.z * sp_diffuse;
+                    throughput = f3(k_d.x * kPi / den, k_d.y * kPi / den, k_d.z * kPi / den);
+                } else {
+                    const F3 S = -I + (2.0f * dot3(I, norm)) * norm;   // reflect, RTBase.cpp:22-24
+                    const float lobe_cos = cr_pow(bu2, 1.0f / (n_s + 1.0f));   // RTBase.cpp:39-49
+                    const F3 micro_O = vec_sin_cos(kTwoPi * bu1, sqrtf(1.0f - lobe_cos * lobe_cos), lobe_cos);
+                    O = mul3(span_tangent_space(S), micro_O);
+                    const float den = (n_s + 1.0f) * (1.0f - sp_diffuse);
+                    throughput = f3(k_s.x * kTwoPi / den, k_s.y * kTwoPi / den, k_s.z * kTwoPi / den);
+                }
+                const float cos_the = dot3(O, norm);
+                const F3 tc3 = throughput * cos_the;
+                st.ax = st.ax * tc3.x; st.ay = st.ay * tc3.y; st.az = st.az * tc3.z;
+                new_o = hit_pt + kRayOffset * norm; new_d = O;   // Ray{hit_pt, O, norm}, RTBase.cpp:117-122
+                go_on = true;
+            }
+        }
+    }
+    st.k = draw.k;
+    if (go_on && !last_bounce) {
+        store_ray(W, i, new_o, new_d);
+    } else {
+        retire(W, i, st);
+    }
+    W.state[i] = st;
+}
+
+// ---- keeping the first max_vpl_count records in path order --------------------------------------
+// Running totals over the blocks of paths walked so far.
+struct Acc {
+    unsigned size;        // VPL records kept
+    unsigned contrib;     // paths that supplied at least one of them (the renumbered path id of the next one)
+    unsigned n_paths;     // set with `done`: paths counted by the serial loop
+    unsigned done;        // record number max_vpl_count has been written
+    unsigned error;
+    unsigned pad[3];
+};
+
+// per path: (records, 1 if any) packed as low/high halves of one 64-bit sum
+__device__ __forceinline__ unsigned long long path_counts(const PathState& s) {
+    return (unsigned long long)s.n_vpl | ((unsigned long long)(s.n_vpl ? 1u : 0u) << 32);
+}
+__device__ __forceinline__ unsigned long long block_exclusive_scan_u64(unsigned long long v, unsigned long long* lds,
+                                                                       unsigned long long& total) {
+    const unsigned t = threadIdx.x;
+    lds[t] = v;
+    __syncthreads();
+    for (unsigned off = 1; off < 256; off <<= 1) {
+        const unsigned long long add = t >= off ? lds[t - off] : 0ull;
+        __syncthreads();
+        lds[t] += add;
+        __syncthreads();
+    }
+    total = lds[255];
+    const unsigned long long excl = lds[t] - v;
+    __syncthreads();
+    return excl;
+}
+__global__ void __launch_bounds__(256) vpl_block_sums_kernel(const PathState* st, unsigned n, unsigned long long* sums) {
+    __shared__ unsigned long long lds[256];
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    unsigned long long total;
+    (void)block_exclusive_scan_u64(i < n ? path_counts(st[i]) : 0ull, lds, total);
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+// one workgroup: block sums -> exclusive offsets
+__global__ void __launch_bounds__(256) vpl_scan_sums_kernel(unsigned long long* sums, unsigned n_blocks) {
+    __shared__ unsigned long long lds[256];
+    unsigned long long run = 0ull;
+    for (unsigned b0 = 0; b0 < n_blocks; b0 += 256u) {
+        const unsigned b = b0 + threadIdx.x;
+        const unsigned long long v = b < n_blocks ? sums[b] : 0ull;
+        unsigned long long total;
+        const unsigned long long excl = block_exclusive_scan_u64(v, lds, total);
+        if (b < n_blocks) sums[b] = run + excl;
+        run += total;
+    }
+}
+__global__ void __launch_bounds__(256) vpl_gather_kernel(const PathState* st, const VplRec* slots, unsigned first,
+                                                         unsigned n, const unsigned long long* sums, unsigned max_vpl,
+                                                         Acc* acc, VplRec* out) {
+    __shared__ unsigned long long lds[256];
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    const unsigned long long mine = i < n ? path_counts(st[i]) : 0ull;
+    unsigned long long total;
+    const unsigned long long excl = sums[blockIdx.x] + block_exclusive_scan_u64(mine, lds, total);
+    const unsigned base = acc->size + (unsigned)(excl & 0xFFFFFFFFull);
+    const unsigned new_id = acc->contrib + (unsigned)(excl >> 32);
+    const unsigned cnt = (unsigned)(mine & 0xFFFFFFFFull);
+    for (unsigned j = 0; j < cnt; ++j) {
+        const unsigned pos = base + j;
+        if (pos >= max_vpl) break;
+        VplRec v = slots[(size_t)i * kGiBounces + j];
+        v.w[11] = new_id;   // LightArray::normalizeIntensity's renumbering: ids count the contributing paths
+        out[pos] = v;
+        if (pos + 1u == max_vpl) {   // the serial loop stops inside this path: it is the last one counted
+            acc->n_paths = first + i + 1u;
+            acc->done = 1u;
+        }
+    }
+}
+// after the gather of a block of paths (single thread): totals for the next block
+__global__ void vpl_advance_kernel(const PathState* st, const unsigned long long* sums, unsigned n, Acc* acc,
+                                   const unsigned* error) {
+    const unsigned last_block = (n - 1u) / 256u;
+    unsigned long long tot = sums[last_block];
+    for (unsigned i = last_block * 256u; i < n; ++i) tot += path_counts(st[i]);
+    acc->size += (unsigned)(tot & 0xFFFFFFFFull);
+    acc->contrib += (unsigned)(tot >> 32);
+    if (*error) acc->error = 1u;
+}
+__global__ void __launch_bounds__(256) vpl_normalize_kernel(VplRec* out, unsigned n, unsigned n_paths) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float inv = 1.0f / (float)(int)n_paths;   // LightArray.hpp:47
+    for (int k = 4; k < 7; ++k) out[i].w[k] = __float_as_uint(__uint_as_float(out[i].w[k]) * inv);
+}
+
+}  // namespace
+
+extern "C" int gigl_photon_trace_batch(const gigl_scene* s, const gigl_fog* fog, const float* materials, uint32_t n_mat,
+                                       float abs_k, float sca_k, float maj_ext_k, int fog_enabled,
+                                       const float ppl_pos[3], const float ppl_intens[3], const float shoot_dir[3],
+                                       int max_vpl_count, uint64_t seed, uint32_t paths_per_batch, void* vpls_out,
+                                       int* n_vpls_out, uint32_t* n_paths_out) {
+    (void)shoot_dir;   // PhotonTracer.cpp:86-88 builds a frame from it that the walk never uses
+    if (n_vpls_out) *n_vpls_out = 0;
+    if (n_paths_out) *n_paths_out = 0;
+    if (!s || !materials || !ppl_pos || !ppl_intens || !vpls_out || !n_vpls_out)
+        return fail(GIGL_ERR_INVALID, "NULL argument");
+    if (s->device == GIGL_DEVICE_NONE) return fail(GIGL_ERR_NO_DEVICE, "host-only scene: no device to trace on");
+    if (max_vpl_count <= 0 || max_vpl_count > (1 << 22)) return fail(GIGL_ERR_INVALID, "max_vpl_count must be in 1..2^22");
+    if (n_mat == 0) return fail(GIGL_ERR_INVALID, "no materials");
+    const bool fog_on = fog_enabled && fog;
+    if (fog && fog->device != s->device) return fail(GIGL_ERR_INVALID, "fog and scene live on different devices");
+    const uint64_t path_limit = 100ull * (uint64_t)max_vpl_count;   // :180
+    uint64_t per = paths_per_batch ? paths_per_batch : std::max<uint64_t>(4ull * (uint64_t)max_vpl_count, 1024);
+    per = std::min<uint64_t>(std::min<uint64_t>(per, path_limit), 1u << 22);
+    per = (per + 255) & ~255ull;
+    const unsigned P = (unsigned)per, n_blocks = P / 256u;
+
+    DeviceGuard g(s->device);
+    // one allocation: state, rays, hits, ranges, hit triangles, VPL slots, kept records, scan sums, totals, materials
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_state = take((size_t)P * sizeof(PathState)), o_o = take((size_t)P * 16), o_d = take((size_t)P * 16);
+    const size_t o_hits = take((size_t)P * 16), o_rng = take((size_t)P * 8), o_tri = take((size_t)P * 48);
+    const size_t o_slots = take((size_t)P * kGiBounces * sizeof(VplRec));
+    const size_t o_out = take((size_t)max_vpl_count * sizeof(VplRec));
+    const size_t o_sums = take((size_t)n_blocks * 8), o_acc = take(sizeof(Acc)), o_err = take(4);
+    const size_t o_mat = take((size_t)n_mat * 48);
+    char* ws = nullptr;
+    HIP_TRY(hipMalloc((void**)&ws, off));
+    hipStream_t st = nullptr;
+    int rc = GIGL_OK;
+    Acc acc = {};
+    auto run = [&]() -> int {
+        HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        HIP_TRY(hipMemsetAsync(ws + o_acc, 0, (o_err + 4) - o_acc, st));
+        HIP_TRY(hipMemcpyAsync(ws + o_mat, materials, (size_t)n_mat * 48, hipMemcpyHostToDevice, st));
+        WalkParams W = {};
+        W.state = (PathState*)(ws + o_state);
+        W.o_tmin = (float4*)(ws + o_o); W.d_tmax = (float4*)(ws + o_d);
+        W.hits = (const uint4*)(ws + o_hits); W.ranges = (const float2*)(ws + o_rng); W.hit_tri = (const float4*)(ws + o_tri);
+        W.slots = (VplRec*)(ws + o_slots);
+        W.seed = seed;
+        W.materials = (const float*)(ws + o_mat); W.n_mat = n_mat;
+        W.fog_on = fog_on ? 1 : 0;
+        if (fog) {
+            W.fog = fog->fp;
+            W.fog_box = BoxF{fog->fp.mnx, fog->fp.mny, fog->fp.mnz, fog->fp.mxx, fog->fp.mxy, fog->fp.mxz};
+        }
+        W.abs_k = abs_k; W.sca_k = sca_k; W.maj_ext_k = maj_ext_k;
+        for (int a = 0; a < 3; ++a) { W.src[a] = ppl_pos[a]; W.src_int[a] = ppl_intens[a]; }
+        W.error = (unsigned*)(ws + o_err);
+        unsigned long long* sums = (unsigned long long*)(ws + o_sums);
+        Acc* d_acc = (Acc*)(ws + o_acc);
+        VplRec* d_out = (VplRec*)(ws + o_out);
+        uint64_t first = 0;
+        while (first < path_limit) {
+            const unsigned nb = (unsigned)std::min<uint64_t>(P, path_limit - first);
+            const unsigned grid = (nb + 255u) / 256u;
+            W.first = (unsigned)first; W.n = nb;
+            hipLaunchKernelGGL(photon_start_kernel, dim3(grid), dim3(256), 0, st, W);
+            for (int b = 1; b <= kGiBounces; ++b) {
+                int trc = trace_closest_ranges(s, W.o_tmin, W.d_tmax, nb, (uint4*)(ws + o_hits), (float2*)(ws + o_rng),
+                                               (float4*)(ws + o_tri), st);
+                if (trc != GIGL_OK) return trc;
+                hipLaunchKernelGGL(photon_bounce_kernel, dim3(grid), dim3(256), 0, st, W, b == kGiBounces ? 1 : 0);
+            }
+            hipLaunchKernelGGL(vpl_block_sums_kernel, dim3(grid), dim3(256), 0, st, W.state, nb, sums);
+            hipLaunchKernelGGL(vpl_scan_sums_kernel, dim3(1), dim3(256), 0, st, sums, grid);
+            hipLaunchKernelGGL(vpl_gather_kernel, dim3(grid), dim3(256), 0, st, W.state, W.slots, W.first, nb, sums,
+                               (unsigned)max_vpl_count, d_acc, d_out);
+            hipLaunchKernelGGL(vpl_advance_kernel, dim3(1), dim3(1), 0, st, W.state, sums, nb, d_acc, W.error);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(&acc, d_acc, sizeof(Acc), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            if (acc.error) return fail(GIGL_ERR_INVALID, "a hit triangle names a material beyond n_mat");
+            if (acc.done) break;
+            first += nb;
+        }
+        if (!acc.done) {   // :181-184: not enough VPLs within 100 * max_vpl_count paths: the array is cleared
+            if (n_paths_out) *n_paths_out = (uint32_t)path_limit;
+            return GIGL_OK;
+        }
+        hipLaunchKernelGGL(vpl_normalize_kernel, dim3(((unsigned)max_vpl_count + 255u) / 256u), dim3(256), 0, st, d_out,
+                           (unsigned)max_vpl_count, acc.n_paths);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(vpls_out, d_out, (size_t)max_vpl_count * sizeof(VplRec), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        *n_vpls_out = max_vpl_count;
+        if (n_paths_out) *n_paths_out = acc.n_paths;
+        return GIGL_OK;
+    };
+    rc = run();
+    if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    (void)hipFree(ws);
+    return rc;
+}

@@ -995,6 +995,21 @@ int check_batch(const gigl_scene* s, const void* a, const void* b, uint64_t n, c
 
 }  // namespace
 
+// Closest-hit batch that also leaves, per ray, the (t_min, t_max) KdTree::intersect ends with and the hit
+// triangle's record: what Scene::trace's callers read from the ray afterwards (gigl_photon.hip).
+int gd::trace_closest_ranges(const gigl_scene* s, const float4* o_tmin, const float4* d_tmax, unsigned n, uint4* hits,
+                             float2* ranges, float4* hit_tri, hipStream_t st) {
+    if (n == 0) return GIGL_OK;
+    TraceParams P = {};
+    P.n = n;
+    P.o_tmin = o_tmin;
+    P.d_tmax = d_tmax;
+    P.hits = hits;
+    P.ranges = ranges;
+    P.hit_tri = hit_tri;
+    return launch_trace<false, 0>(s, P, st);
+}
+
 int gd::scene_clone_to_device(const gigl_scene* src, int device, gigl_scene** out) {
     *out = nullptr;
     if (!src || src->device == GIGL_DEVICE_NONE) return fail(GIGL_ERR_INVALID, "clone needs a device scene");

@@ -30,7 +30,7 @@ SYMBOLS = [
     "gigl_depth_buffer_device", "gigl_combine_device", "gigl_debug_check_layout", "gigl_scene_layout",
     "gigl_trace_closest_noalloc_device", "gigl_multi_create", "gigl_multi_destroy", "gigl_multi_device_count",
     "gigl_multi_trace_closest_device", "gigl_multi_trace_closest", "gigl_shadow_batch_fused_device",
-    "gigl_debug_launch_info",
+    "gigl_debug_launch_info", "gigl_photon_trace_batch",
 ]
 
 
@@ -92,6 +92,7 @@ def lib():
         L.gigl_trace_any_device.argtypes = [vp, vp, vp, u64, vp, vp]
         L.gigl_trace_any.argtypes = [vp, vp, vp, u64, vp]
         L.gigl_trace_one.argtypes = [vp, vp, vp, f, f, i, vp, vp, vp, vp]
+        L.gigl_photon_trace_batch.argtypes = [vp, vp, vp, u32, f, f, f, i, vp, vp, vp, i, u64, u32, vp, vp, vp]
         L.gigl_camera_setup.argtypes = [vp, vp, vp, f, i, i, vp]
         L.gigl_gen_primary_rays_device.argtypes = [vp, vp, i, u64, u64, vp, vp, vp]
         L.gigl_trace_primary_device.argtypes = [vp, vp, i, u64, u64, vp, vp]
@@ -282,6 +283,20 @@ class Scene:
                                     C.byref(hit), _p(rec), _p(nrm), _p(rng)))
         self.last_range = rng
         return bool(hit.value), rec[0], nrm
+
+    def photon_trace_batch(self, materials, fog, abs_k, sca_k, maj_ext_k, fog_enabled, ppl_pos, ppl_intens,
+                           shoot_dir, max_vpl_count, seed, paths_per_batch=0):
+        """rt::PhotonTracer::trace as ray batches, substream mode (include/gigl_rt.h):
+        (n_vpls, 96-byte VPL records as a (max_vpl_count, 24) uint32 array, n_paths)."""
+        materials = _f32(materials).reshape(-1, 12)
+        vpls = np.zeros((max_vpl_count, 24), np.uint32)
+        n_vpls, n_paths = C.c_int(0), C.c_uint32(0)
+        _check(lib().gigl_photon_trace_batch(self.h, fog.h if fog is not None else None, _p(materials), len(materials),
+                                             abs_k, sca_k, maj_ext_k, int(fog_enabled), _p(_f32(ppl_pos)),
+                                             _p(_f32(ppl_intens)), _p(_f32(shoot_dir)), max_vpl_count,
+                                             int(seed) & (2 ** 64 - 1), paths_per_batch, _p(vpls), C.byref(n_vpls),
+                                             C.byref(n_paths)))
+        return n_vpls.value, vpls, n_paths.value
 
     # ---- device-pointer calls (ints from torch.Tensor.data_ptr()) ----
     def trace_closest_device(self, o_ptr, d_ptr, n, hits_ptr, stream=0):

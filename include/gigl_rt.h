@@ -153,6 +153,33 @@ int gigl_trace_closest_noalloc_device(const gigl_scene* s, const void* o_tmin, c
 int gigl_trace_one(const gigl_scene* s, const float o[3], const float d[3], float t_min, float t_max,
                    int is_vis_ray, int* hit_out, gigl_hit* hit_rec, float normal_out[3], float range_out[2]);
 
+/* rt::PhotonTracer::trace (Source/RT/PhotonTracer.cpp:78-188) as ray batches: VPL generation for one
+ * primary light, every scene.trace of every bounce a closest-hit batch over a block of paths, every
+ * Woodcock step, Russian roulette, VPL record and next ray computed on the device (one lane per path).
+ * Replaces the call at Source/Common/Renderer.cpp:223.
+ *
+ * SUBSTREAM MODE (the build's definition; PARITY UNPINNED — the reference draws every number from one
+ * global std::mt19937, which makes path p depend on paths 0..p-1 and cannot be batched): path p
+ * (0-based) draws u(p,k) = (splitmix64(key(p) + k * 0x9E3779B97F4A7C15) >> 40) * 2^-24, k = 0, 1, ...,
+ * with key(p) = splitmix64(seed ^ splitmix64(p)); cos, sin, log and pow are the double-precision
+ * functions rounded to float.  Every other operation, the order of the draws within a path, the
+ * stopping rule (the path that supplies VPL number max_vpl_count is the last one counted; at most
+ * 100 * max_vpl_count paths, else no VPLs), LightArray::normalizeIntensity's renumbering and scaling
+ * (Source/VPL/LightArray.hpp:46-66) are the reference's.  The serial single-stream walk remains
+ * available through gigl_trace_one (gigl_amd/host/gigl_host.hpp).
+ *
+ * materials: host float[12 * n_mat] = (k_d, -, k_s, n_s, k_e, -) per material (rt::PhongMaterial,
+ * Source/RT/RTBase.h:53-78), indexed by the material ids given to gigl_scene_create.  fog may be NULL
+ * (then fog_enabled is ignored).  paths_per_batch: paths walked per block (0: the engine's choice).
+ * vpls_out: host, 96 bytes per VPL (Source/VPL/PointLight.h:66-77), max_vpl_count records.
+ * *n_vpls_out = max_vpl_count, or 0 when 100 * max_vpl_count paths did not supply them
+ * (PhotonTracer.cpp:181-184); *n_paths_out = paths counted. */
+int gigl_photon_trace_batch(const gigl_scene* s, const gigl_fog* fog, const float* materials, uint32_t n_mat,
+                            float abs_k, float sca_k, float maj_ext_k, int fog_enabled,
+                            const float ppl_pos[3], const float ppl_intens[3], const float shoot_dir[3],
+                            int max_vpl_count, uint64_t seed, uint32_t paths_per_batch, void* vpls_out,
+                            int* n_vpls_out, uint32_t* n_paths_out);
+
 /* PerspectiveCamera (Source/Common/Camera.cpp:15-33): cam = pos, bottom_left, step_x, step_y. */
 int gigl_camera_setup(const float pos[3], const float dir[3], const float up[3], float h_fov,
                       int res_x, int res_y, float cam_out[12]);

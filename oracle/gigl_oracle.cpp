@@ -929,19 +929,64 @@ void ora_make_density(const int res[3], float freq, float ampl, uint8_t* out) {
     }
 }
 
-/* Source/RT/PhotonTracer.cpp:78-188 with an explicit RNG stream.  PARITY UNPINNED. */
-int ora_photon_trace(const ora_scene* s, const float* materials, uint32_t n_mat, const ora_fog* fog,
-                     float abs_k, float sca_k, float maj_ext_k, int fog_enabled, const float ppl_pos[3],
-                     const float ppl_intens[3], const float shoot_dir[3], int max_vpl_count,
-                     const float* rng, uint64_t n_rng, void* vpls_out, uint32_t* n_paths_out,
-                     uint64_t* n_rng_used_out) {
-    (void)n_mat;
+}  /* extern "C" */
+
+namespace {
+/* Where the walk's random numbers come from.  Stream mode: one caller-supplied sequence consumed in
+ * walk order (the reference's single global std::mt19937, Source/Common/Random.cpp:11-18).
+ * Substream mode (the build's own definition, for the batched device walk): path p draws from a
+ * counter-based stream of its own, u(p, k) = top 24 bits of splitmix64(key(p) + k * gamma) * 2^-24 with
+ * key(p) = splitmix64(seed ^ splitmix64(p)), so paths can be walked in any order or all at once. */
+inline uint64_t splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+struct WalkDraw {
+    const float* rng = nullptr; uint64_t n_rng = 0, rp = 0;   /* stream mode */
+    bool substreams = false; uint64_t seed = 0, key = 0; uint32_t k = 0;
+    bool starved = false;
+    uint64_t n_drawn = 0;
+    void begin_path(uint p) {
+        if (substreams) { key = splitmix64(seed ^ splitmix64((uint64_t)p)); k = 0; }
+    }
+    float operator()() {
+        ++n_drawn;
+        if (substreams) {
+            const uint64_t z = splitmix64(key + (uint64_t)k * 0x9E3779B97F4A7C15ull);
+            ++k;
+            return (float)(uint32_t)(z >> 40) * 5.9604644775390625e-8f;   /* 2^-24: [0, 1) */
+        }
+        if (rp < n_rng) return rng[rp++];
+        starved = true;
+        return 0.0f;
+    }
+};
+/* The walk's transcendental functions.  Stream mode calls the host's float libm (as the reference calls
+ * MSVC's).  Substream mode rounds the double-precision function to float: the correctly rounded float
+ * result (up to double rounding at exact ties of the double result, probability ~2^-29 per call),
+ * which the device can reproduce bit for bit; a float libm differs between platforms in the last place. */
+struct WalkMath {
+    bool cr;
+    float cos_(float x) const { return cr ? (float)cos((double)x) : cosf(x); }
+    float sin_(float x) const { return cr ? (float)sin((double)x) : sinf(x); }
+    float log_(float x) const { return cr ? (float)log((double)x) : logf(x); }
+    float pow_(float x, float y) const { return cr ? (float)pow((double)x, (double)y) : powf(x, y); }
+    V3 vec_sin_cos(float phi, float sin_the, float cos_the) const {                  /* RTBase.h:44-50 */
+        return v3(sin_the * cos_(phi), sin_the * sin_(phi), cos_the);
+    }
+};
+
+/* Source/RT/PhotonTracer.cpp:78-188.  PARITY UNPINNED. */
+int photon_walk(const ora_scene* s, const float* materials, const ora_fog* fog,
+                float abs_k, float sca_k, float maj_ext_k, int fog_enabled, const float ppl_pos[3],
+                const float ppl_intens[3], const float shoot_dir[3], int max_vpl_count,
+                WalkDraw& draw, const WalkMath M, void* vpls_out, uint32_t* n_paths_out) {
     struct VPL96 { float w_pos[3]; uint type; float intens[3]; float sca_k; float w_inc[3]; uint path_id;
                    float w_norm[3]; uint pad1; float k_d[3]; uint pad2; float k_s[3]; float n_s; };
     VPL96* out = (VPL96*)vpls_out;
-    uint64_t rp = 0;
-    bool starved = false;
-    auto draw = [&]() -> float { if (rp < n_rng) return rng[rp++]; starved = true; return 0.0f; };
+    bool& starved = draw.starved;
     const V3 src = v3(ppl_pos[0], ppl_pos[1], ppl_pos[2]);
     const V3 src_int = v3(ppl_intens[0], ppl_intens[1], ppl_intens[2]);
     const V3 sdir = v3(shoot_dir[0], shoot_dir[1], shoot_dir[2]);
@@ -952,6 +997,7 @@ int ora_photon_trace(const ora_scene* s, const float* materials, uint32_t n_mat,
     uint n_paths = 0;
     do {
         ++n_paths;
+        draw.begin_path(n_paths - 1);
         /* :86-88 — the draw happens only when source.z <= MAX_FOG_HEIGHT; `up` and the
          * tangent space built from it are never used. */
         if (src.z <= MAX_FOG_HEIGHT) { (void)draw(); }
@@ -962,7 +1008,7 @@ int ora_photon_trace(const ora_scene* s, const float* materials, uint32_t n_mat,
         const float u0 = draw();
         const float phi = TWO_PI * u0;
         const float sin_the = sqrtf(1.0f - u1 * u1);
-        const V3 dir = gen_vec_sin_cos(phi, sin_the, u1);
+        const V3 dir = M.vec_sin_cos(phi, sin_the, u1);
         const float pdf = 0.5f * INV_PI;
         Ray ray = make_ray(src, dir);
         const float ia = 1.0f / pdf;
@@ -981,7 +1027,7 @@ int ora_photon_trace(const ora_scene* s, const float* materials, uint32_t n_mat,
                 if (0.0f != maj_ext_k) {
                     float d_event = ray.t_min, p_event = 0.0f;
                     while (d_event < ray.t_max && p_event < draw()) {
-                        const float dt = -logf(1.0f - draw()) / maj_ext_k;
+                        const float dt = -M.log_(1.0f - draw()) / maj_ext_k;
                         d_event += dt;
                         const V3 s_pos = pt_at(ray, d_event);
                         const float ext_k = ext_k_sum * sample_density(*fog, s_pos);
@@ -1013,7 +1059,7 @@ int ora_photon_trace(const ora_scene* s, const float* materials, uint32_t n_mat,
                         const float cos_the = 0.5f / fabsf(HG_G) * (1.0f + HG_G * HG_G - q * q);
                         const float sin_t = sqrtf(1.0f - cos_the * cos_the);
                         const M3 m2m = span_tangent_space(I);
-                        const V3 O = mul(m2m, gen_vec_sin_cos(hphi, sin_t, cos_the));
+                        const V3 O = mul(m2m, M.vec_sin_cos(hphi, sin_t, cos_the));
                         attenuation = attenuation * 1.0f;
                         ray = make_ray(event_pt, O);
                         continue;
@@ -1051,13 +1097,16 @@ int ora_photon_trace(const ora_scene* s, const float* materials, uint32_t n_mat,
                     V3 O, throughput;
                     if (u_rand < sp_diffuse) {
                         const M3 m2m = span_tangent_space(norm);
-                        const V3 micro_O = gen_cos_rand_hemi_dir(bu1, bu2);
+                        /* genCosRandHemiDir, RTBase.cpp:27-36 */
+                        const V3 micro_O = M.vec_sin_cos(TWO_PI * bu1, sqrtf(1.0f - bu2), sqrtf(bu2));
                         O = mul(m2m, micro_O);
                         throughput = (k_d * PI) / (micro_O.z * sp_diffuse);
                     } else {
                         const V3 S = -I + (2.0f * dot(I, norm)) * norm;                 /* reflect, :22-24 */
                         const M3 m2m = span_tangent_space(S);
-                        const V3 micro_O = gen_cos_pow_rand_hemi_dir(bu1, bu2, n_s);
+                        /* genCosPowRandHemiDir, RTBase.cpp:39-49 */
+                        const float lobe_cos = M.pow_(bu2, 1.0f / (n_s + 1.0f));
+                        const V3 micro_O = M.vec_sin_cos(TWO_PI * bu1, sqrtf(1.0f - lobe_cos * lobe_cos), lobe_cos);
                         O = mul(m2m, micro_O);
                         const float sp_glossy = 1.0f - sp_diffuse;
                         throughput = (k_s * TWO_PI) / ((n_s + 1.0f) * sp_glossy);
@@ -1072,7 +1121,6 @@ int ora_photon_trace(const ora_scene* s, const float* materials, uint32_t n_mat,
         if (starved) break;
     } while (size < max_vpl_count && n_paths < (uint)(100 * max_vpl_count));
     if (n_paths_out) *n_paths_out = n_paths;
-    if (n_rng_used_out) *n_rng_used_out = rp;
     if (starved) return -1;
     if (size < max_vpl_count) return 0;                                /* :181-184 */
     /* LightArray::normalizeIntensity, Source/VPL/LightArray.hpp:46-66 */
@@ -1084,6 +1132,39 @@ int ora_photon_trace(const ora_scene* s, const float* materials, uint32_t n_mat,
         out[i].intens[0] *= inv_n_paths; out[i].intens[1] *= inv_n_paths; out[i].intens[2] *= inv_n_paths;
     }
     return size;
+}
+}  /* namespace */
+
+extern "C" {
+
+/* PhotonTracer::trace with an explicit RNG stream consumed in walk order (the reference's order). */
+int ora_photon_trace(const ora_scene* s, const float* materials, uint32_t n_mat, const ora_fog* fog,
+                     float abs_k, float sca_k, float maj_ext_k, int fog_enabled, const float ppl_pos[3],
+                     const float ppl_intens[3], const float shoot_dir[3], int max_vpl_count,
+                     const float* rng, uint64_t n_rng, void* vpls_out, uint32_t* n_paths_out,
+                     uint64_t* n_rng_used_out) {
+    (void)n_mat;
+    WalkDraw draw;
+    draw.rng = rng; draw.n_rng = n_rng;
+    const int n = photon_walk(s, materials, fog, abs_k, sca_k, maj_ext_k, fog_enabled, ppl_pos, ppl_intens,
+                              shoot_dir, max_vpl_count, draw, WalkMath{false}, vpls_out, n_paths_out);
+    if (n_rng_used_out) *n_rng_used_out = draw.rp;
+    return n;
+}
+
+/* The same walk in substream mode (WalkDraw, WalkMath above): what gigl_photon_trace_batch computes. */
+int ora_photon_trace_substreams(const ora_scene* s, const float* materials, uint32_t n_mat, const ora_fog* fog,
+                                float abs_k, float sca_k, float maj_ext_k, int fog_enabled,
+                                const float ppl_pos[3], const float ppl_intens[3], const float shoot_dir[3],
+                                int max_vpl_count, uint64_t seed, void* vpls_out, uint32_t* n_paths_out,
+                                uint64_t* n_draws_out) {
+    (void)n_mat;
+    WalkDraw draw;
+    draw.substreams = true; draw.seed = seed;
+    const int n = photon_walk(s, materials, fog, abs_k, sca_k, maj_ext_k, fog_enabled, ppl_pos, ppl_intens,
+                              shoot_dir, max_vpl_count, draw, WalkMath{true}, vpls_out, n_paths_out);
+    if (n_draws_out) *n_draws_out = draw.n_drawn;
+    return n;
 }
 
 }  /* extern "C" */

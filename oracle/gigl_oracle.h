@@ -149,6 +149,15 @@ int ora_photon_trace(const ora_scene* s, const float* materials, uint32_t n_mat,
                      const float shoot_dir[3], int max_vpl_count, const float* rng,
                      uint64_t n_rng, void* vpls_out, uint32_t* n_paths_out,
                      uint64_t* n_rng_used_out);
+/* The same walk in SUBSTREAM mode, the build's own definition for the batched device walk
+ * (gigl_photon_trace_batch): path p (0-based) draws u(p,k) = (splitmix64(key(p) + k*0x9E3779B97F4A7C15) >> 40) * 2^-24
+ * with key(p) = splitmix64(seed ^ splitmix64(p)), and cos/sin/log/pow are the double-precision functions
+ * rounded to float.  Every other operation is ora_photon_trace's.  PARITY UNPINNED. */
+int ora_photon_trace_substreams(const ora_scene* s, const float* materials, uint32_t n_mat,
+                                const ora_fog* fog, float abs_k, float sca_k, float maj_ext_k,
+                                int fog_enabled, const float ppl_pos[3], const float ppl_intens[3],
+                                const float shoot_dir[3], int max_vpl_count, uint64_t seed,
+                                void* vpls_out, uint32_t* n_paths_out, uint64_t* n_draws_out);
 
 
 /* Software shading stage: Surface.frag main() (Source/Shaders/Surface.frag:290-343) for one frame over

@@ -78,6 +78,11 @@ def lib():
         L.ora_photon_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_float, C.c_float,
                                        C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                        C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ora_photon_trace_substreams.restype = C.c_int
+        L.ora_photon_trace_substreams.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_float,
+                                                  C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p,
+                                                  C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p,
+                                                  C.c_void_p]
         L.ora_shade_surface.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint64,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                                         C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -298,6 +303,20 @@ def photon_trace(scene, materials, fog, abs_k, sca_k, maj_ext_k, fog_enabled, pp
                                _p(_f32(ppl_intens)), _p(_f32(shoot_dir)), max_vpl_count, _p(rng), len(rng),
                                _p(vpls), C.byref(n_paths), C.byref(n_used))
     return n, vpls, n_paths.value, n_used.value
+
+
+def photon_trace_substreams(scene, materials, fog, abs_k, sca_k, maj_ext_k, fog_enabled, ppl_pos, ppl_intens,
+                            shoot_dir, max_vpl_count, seed):
+    """PhotonTracer::trace in substream mode (see ora_photon_trace_substreams): (n, vpls, n_paths, n_draws)."""
+    materials = _f32(materials).reshape(-1, 12)
+    vpls = np.zeros(max_vpl_count, VPL_DTYPE)
+    n_paths, n_draws = C.c_uint32(), C.c_uint64()
+    n = lib().ora_photon_trace_substreams(scene.h, _p(materials), len(materials),
+                                          fog.ref() if fog is not None else None, abs_k, sca_k, maj_ext_k,
+                                          int(fog_enabled), _p(_f32(ppl_pos)), _p(_f32(ppl_intens)),
+                                          _p(_f32(shoot_dir)), max_vpl_count, int(seed) & (2**64 - 1), _p(vpls),
+                                          C.byref(n_paths), C.byref(n_draws))
+    return n, vpls, n_paths.value, n_draws.value
 
 
 def shade_surface(scene, fog, cam_pos, res_x, res_y, first, ro, rd, hits, materials, ppls, vpls, occluded,

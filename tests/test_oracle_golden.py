@@ -86,3 +86,23 @@ def test_bbox_intersect_cases(oracle_cornell):
     # 0 * inf = NaN when the origin lies on a slab and d is 0 on that axis: all compares false
     hit, e, x = O.bbox_intersect(box, [0, 273, -800], [0, 0, 1], 0.0, 3.4e38)
     assert isinstance(hit, bool)
+
+
+def test_substream_walk_is_order_independent(cornell, oracle_cornell, density, fog_box):
+    """ora_photon_trace_substreams (the mode gigl_photon_trace_batch computes): path p draws from its own
+    counter-based stream, so the VPLs of a 150-record walk are the first 150 of a 400-record walk, up to
+    the division by the path count (LightArray.hpp:46-66), and another seed gives another set."""
+    from gigl_amd import scene_io as S
+    from oracle import oracle_py as O
+    fog = O.Fog(density, fog_box, np.float32(S.ABS_K) + np.float32(S.SCA_K))
+    args = (oracle_cornell, cornell["materials"], fog, S.ABS_K, S.SCA_K, S.MAJ_EXT_K, 1, S.PRIM_PL_POS, S.PRIM_PL_INTENS,
+            [0, -1, 0])
+    n_a, a, paths_a, draws_a = O.photon_trace_substreams(*args, 150, 42)
+    n_b, b, paths_b, draws_b = O.photon_trace_substreams(*args, 400, 42)
+    assert n_a == 150 and n_b == 400 and paths_a < paths_b and draws_a < draws_b
+    for k in ("w_pos", "type", "sca_k", "w_inc", "path_id", "w_norm", "k_d", "k_s", "n_s"):
+        assert np.array_equal(a[k], b[k][:150]), k
+    scale = np.float32(paths_b) / np.float32(paths_a)
+    assert np.allclose(a["intens"], b["intens"][:150] * scale, rtol=1e-6)
+    n_c, c, _, _ = O.photon_trace_substreams(*args, 150, 43)
+    assert n_c == 150 and not np.array_equal(a["w_pos"], c["w_pos"])
