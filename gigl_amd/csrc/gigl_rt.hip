@@ -758,13 +758,13 @@ namespace {
 
 struct Options {
     int stack_lds = 8;        // LDS entries per lane (12 bytes each): 8, 12, 16 or 32; 8 keeps 6 workgroups per CU
-    int refill_thresh = 32;   // idle lanes that trigger a refill (closest-hit / atomic any-hit)
+    int refill_thresh = 24;   // idle lanes that trigger a refill (closest-hit / atomic any-hit)
     int any_atomic = -1;      // 0: any-hit waves own 64 consecutive rays, one store per wave; 1: lane refill +
                               // atomicOr; -1: the engine's choice (1)
     int blocks_per_cu = 0;    // 0: occupancy query
     int chunk = 256;          // rays per work-counter atomic
     int guided = 4;           // 0: fixed chunks; k: near the end a request is remaining / (k * waves)
-    int t_exit = 16;          // see trace_kernel: T-phase exit threshold (1..64)
+    int t_exit = 20;          // see trace_kernel: T-phase exit threshold (1..64)
     int stats = 0;            // 1: closest-hit launches run the instrumented build and keep 8 counters
     int sort_rays = 0;        // explicit-ray batches: 1 regroup rays before tracing, 0 never, -1 deep tree + large
                               // batch.  Off by default: on MI355X the two atomic passes (2.9 ms per 2^24 rays)
@@ -773,7 +773,8 @@ struct Options {
     int treelet_levels = 3;   // read at gigl_scene_create: levels of child pairs per cache-line treelet (1..5)
     int leaf_blocks = -1;     // read at gigl_scene_create (triple layout): leaves with at least this many prims read
                               // a private block of triangle copies (kd_layout.h); 0 never; -1 the engine's choice:
-                              // 2 when tree and triangle table exceed the 256 MB Infinity Cache anyway, else 0
+                              // 2 when tree and triangle table exceed the 256 MB Infinity Cache anyway, else 6
+                              // (only the big leaves: +14 % bytes on S(158), still cache resident, +1 %)
     int build_threads = 0;    // read at gigl_scene_create: host threads of the tree build (0: min(16, cores)); the
                               // tree does not depend on it
     int layout = 2;           // read at gigl_scene_create (kd_layout.h): 0 level treelets + separate id lists,
@@ -1230,7 +1231,7 @@ int gigl_scene_create(const float* verts, uint32_t n_verts, const uint32_t* tris
         // it): worth it only when the structure is served from HBM anyway.  Below the Infinity Cache's size
         // the shared 64-byte table stays on-die and wins (kernels).
         const size_t plain_bytes = s->tree.nodes.size() * 6 + (size_t)n_tris * 4 * kTriStride * 4;
-        dtree.leaf_block_min = leaf_blocks < 0 ? (plain_bytes > (size_t)200 << 20 ? 2u : 0u) : (uint32_t)leaf_blocks;
+        dtree.leaf_block_min = leaf_blocks < 0 ? (plain_bytes > (size_t)200 << 20 ? 2u : 6u) : (uint32_t)leaf_blocks;
         if (!gigl::layout_triples(s->tree, dtree)) { layout = 1; dtree = gigl::DeviceTree(); }   // beyond the record encoding: fall back
     }
     if (layout == 1) gigl::layout_clustered(s->tree, dtree);

@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 TAG=$1; shift
 mkdir -p build/obj_$TAG
 FLAGS="-std=c++17 -O3 -fPIC -ffp-contract=off -fno-fast-math --offload-arch=gfx950 $*"
-for f in gigl_rt gigl_fog gigl_shade gigl_multi; do
+for f in gigl_rt gigl_fog gigl_shade gigl_multi gigl_photon; do
   /opt/rocm/bin/hipcc $FLAGS -c -o build/obj_$TAG/$f.o gigl_amd/csrc/$f.hip &
 done
 /opt/rocm/bin/hipcc $FLAGS -c -o build/obj_$TAG/kd_build.o gigl_amd/csrc/kd_build.cpp &
