@@ -83,7 +83,7 @@ def git_head():
         return None
 
 
-def traffic_from_profiles(key, layout):
+def traffic_from_profiles(key, layout, n_rays=1 << 24):
     """HBM-side bytes per launch from the committed PMC passes (profiles/traffic.json), with where the
     number comes from: bench.py cannot collect counters itself, so this is NOT measured by this run."""
     tp = os.path.join(ROOT, "profiles", "traffic.json")
@@ -100,7 +100,11 @@ def traffic_from_profiles(key, layout):
     src = {"file": "profiles/traffic.json", "from": ent.get("source"), "commit": ent.get("commit"),
            "fetch_size_bytes": ent.get("fetch_size_bytes"), "tcc_miss_per_ray": ent.get("tcc_miss_per_ray"),
            "note": "constant from a committed rocprofv3 --pmc pass of the same command, not measured by this run"}
-    return ent.get("hbm_bytes_per_launch"), src
+    b = ent.get("hbm_bytes_per_launch")
+    if b is not None and n_rays != (1 << 24):   # the passes were taken on 2^24-ray launches
+        b = b * n_rays / float(1 << 24)
+        src["note"] += "; scaled per ray from a 2^24-ray launch to %d rays" % n_rays
+    return b, src
 
 
 def kernel_name(layout, closest=True, gen="explicit rays"):
@@ -294,7 +298,7 @@ def main():
         k_ms = float(np.mean(kern_ms))
         # per GPU: one launch over this rank's rays
         achieved = bytes_per_ray * n / (k_ms * 1e-3) / 1e9 if bytes_per_ray is not None else None
-        traffic, traffic_src = traffic_from_profiles("bounce" if default_workload else "bounce_s%d" % tess, layout)
+        traffic, traffic_src = traffic_from_profiles("bounce" if tess == 158 else "bounce_s%d" % tess, layout, n)
         per_cu, n_cus = scene.launch_info()
         out = {
             "metric": "Mrays/s (incoherent closest-hit)", "value": round(value, 3), "unit": "Mrays/s",
