@@ -75,6 +75,8 @@ int gigl_fog_create(const uint8_t* dens, const int res[3], const float box[6], f
     if (!dens || !res || !box) return fail(GIGL_ERR_INVALID, "NULL argument");
     if (res[0] <= 0 || res[1] <= 0 || res[2] <= 0 || (int64_t)res[0] * res[1] * res[2] > (1ll << 30))
         return fail(GIGL_ERR_INVALID, "bad volume resolution");
+    if ((uint64_t)(res[0] + 1ll) * (uint64_t)(res[1] + 1ll) * (uint64_t)(res[2] + 1ll) >= (1ull << 31))
+        return fail(GIGL_ERR_TOO_LARGE, "density volume too large for the brick table (2^31 bricks)");
     if (n_intervals < 1 || n_intervals > 4096) return fail(GIGL_ERR_INVALID, "n_intervals must be in 1..4096");
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)

@@ -146,8 +146,9 @@ __device__ __forceinline__ float fog_filter(const FogParams& F, float nx, float 
     // either b, so the filtered value is the same bit for bit.
     const unsigned bx = (unsigned)x0 + 1u, by = (unsigned)y0 + 1u, bz = (unsigned)z0 + 1u;
     uint2 w = make_uint2(0u, 0u);   // every texel outside: the lerps still run (inf/NaN weights propagate)
-    if (bx <= (unsigned)F.rx && by <= (unsigned)F.ry && bz <= (unsigned)F.rz)
-        w = F.bricks[bx + (size_t)by * (unsigned)(F.rx + 1) + (size_t)bz * (unsigned)(F.rx + 1) * (unsigned)(F.ry + 1)];
+    // 32-bit index: gigl_fog_create keeps the brick count below 2^31
+    if ((bx <= (unsigned)F.rx) & (by <= (unsigned)F.ry) & (bz <= (unsigned)F.rz))
+        w = F.bricks[bx + (by + bz * (unsigned)(F.ry + 1)) * (unsigned)(F.rx + 1)];
     const float d000 = byte_unorm(w.x & 0xFFu), d100 = byte_unorm((w.x >> 8) & 0xFFu);
     const float d010 = byte_unorm((w.x >> 16) & 0xFFu), d110 = byte_unorm(w.x >> 24);
     const float d001 = byte_unorm(w.y & 0xFFu), d101 = byte_unorm((w.y >> 8) & 0xFFu);
