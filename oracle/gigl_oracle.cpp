@@ -1,5 +1,6 @@
 /*
  * gigl_oracle.cpp — CPU ORACLE (test infrastructure, NOT product; see gigl_oracle.h).
+ * PARITY UNPINNED against the reference itself (gigl_oracle.h says why).
  *
  * A restatement of the reference's ray-query path in plain scalar C++ (no GLM).
  * Every arithmetic expression keeps the reference's operation order; build with

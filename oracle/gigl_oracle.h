@@ -7,11 +7,13 @@
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it, and only as the
  * checker.  The product library (gigl_amd/lib/libgigl_rt.so) never links or calls it.
  *
- * Pinning: the reference cannot be built in this image without stand-ins for OpenGL,
- * Win32 and the MSVC CRT (see DESIGN.md "Oracle"), so no oracle/_ref exists.  The
- * restatement is pinned against the outputs of the reference recorded when it was run
- * in this container at survey time (tests/golden/survey_facts.json).
- * Sub-paths those facts do not cover are marked "parity unpinned" at their definition.
+ * PARITY UNPINNED.  The reference cannot be built in this image without stand-ins for
+ * OpenGL, Win32 and the MSVC CRT (see DESIGN.md "Oracle"), so no oracle/_ref exists, and the
+ * reference holds no tests, golden vectors or fixtures for this path.  The only outside
+ * evidence is the set of facts SURVEY.md Appendix B recorded from a survey-time build of the
+ * reference that itself used stand-in headers (tests/golden/survey_facts.json; reproduced bit
+ * for bit by tests/test_oracle_golden.py): a consistency check, not a pin.  Sub-paths those
+ * facts do not even touch say so again at their definition.
  *
  * All citations are path:line under /root/reference.
  */
