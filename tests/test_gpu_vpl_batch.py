@@ -83,3 +83,29 @@ def test_vpl_batch_rejects_bad_arguments(setup):
     with pytest.raises(rt.GiglError):   # a material table shorter than the ids the scene's triangles carry
         su["gpu"].photon_trace_batch(np.array(su["mats"], np.float32)[:1], su["gfog"], S.ABS_K, S.SCA_K, S.MAJ_EXT_K, 0,
                                      S.PRIM_PL_POS, S.PRIM_PL_INTENS, [0, -1, 0], 50, 1)
+
+
+@pytest.mark.parametrize("leaf_blocks", [-1, 2])
+def test_vpl_batch_on_a_tessellated_scene(cornell, density, fog_box, leaf_blocks):
+    """The same walk through a deep tree (S(24): 23,040 displaced triangles, stack spills, with and
+    without leaf triangle blocks): hit triangles, their normals and materials come from other code
+    paths than in the 40-triangle box."""
+    from gigl_amd import synth
+    V, T = synth.tessellate(cornell["verts"], cornell["tris"], 24)
+    try:
+        rt.set_option("leaf_blocks", leaf_blocks)
+        gpu = rt.Scene(V, T, device=0, **S.KD_PARAMS)
+    finally:
+        rt.set_option("leaf_blocks", -1)
+    ora = O.OracleScene(V, T, **S.KD_PARAMS)
+    gfog = rt.FogVolume(density, fog_box, S.ABS_K, S.SCA_K)
+    ofog = O.Fog(density, fog_box, np.float32(S.ABS_K) + np.float32(S.SCA_K))
+    su = {"gpu": gpu, "gfog": gfog, "ora": ora, "ofog": ofog, "mats": cornell["materials"]}
+    try:
+        for fog_on, n_vpls, seed in ((1, 600, 11), (0, 3000, 12)):
+            (n, want, want_paths), (g_n, got, got_paths) = _both(su, fog_on, n_vpls, seed)
+            assert n == n_vpls == g_n and got_paths == want_paths
+            assert np.array_equal(got, want)
+    finally:
+        gfog.close()
+        gpu.close()
