@@ -293,6 +293,9 @@ struct gigl_scene {
     void* one_ws = nullptr;        // 256-byte counter block (kept at zero by the kernel) + one wave's spill area
     hipStream_t one_stream = nullptr;
     std::mutex one_mu;
+    // gigl_photon_trace_batch: a workspace kept between calls (grown on demand), used on one_stream under one_mu
+    void* photon_ws = nullptr;
+    size_t photon_ws_bytes = 0;
 };
 
 struct gigl_fog {

@@ -394,13 +394,21 @@ extern "C" int gigl_photon_trace_batch(const gigl_scene* s, const gigl_fog* fog,
     const size_t o_out = take((size_t)max_vpl_count * sizeof(VplRec));
     const size_t o_sums = take((size_t)n_blocks * 8), o_acc = take(sizeof(Acc)), o_err = take(4);
     const size_t o_mat = take((size_t)n_mat * 48);
-    char* ws = nullptr;
-    HIP_TRY(hipMalloc((void**)&ws, off));
-    hipStream_t st = nullptr;
+    // the workspace and the stream belong to the scene and are kept between calls (a 150-VPL set is a
+    // dozen short launches: allocating per call would cost as much as the walk); calls on one scene serialise
+    gigl_scene* ms = const_cast<gigl_scene*>(s);
+    std::lock_guard<std::mutex> lk(ms->one_mu);
+    if (ms->photon_ws_bytes < off) {
+        if (ms->photon_ws) { (void)hipStreamSynchronize(ms->one_stream); (void)hipFree(ms->photon_ws); }
+        ms->photon_ws = nullptr; ms->photon_ws_bytes = 0;
+        HIP_TRY(hipMalloc(&ms->photon_ws, off));
+        ms->photon_ws_bytes = off;
+    }
+    char* const ws = (char*)ms->photon_ws;
+    const hipStream_t st = ms->one_stream;
     int rc = GIGL_OK;
     Acc acc = {};
     auto run = [&]() -> int {
-        HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         HIP_TRY(hipMemsetAsync(ws + o_acc, 0, (o_err + 4) - o_acc, st));
         HIP_TRY(hipMemcpyAsync(ws + o_mat, materials, (size_t)n_mat * 48, hipMemcpyHostToDevice, st));
         WalkParams W = {};
@@ -459,7 +467,6 @@ extern "C" int gigl_photon_trace_batch(const gigl_scene* s, const gigl_fog* fog,
         return GIGL_OK;
     };
     rc = run();
-    if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
-    (void)hipFree(ws);
+    if (rc != GIGL_OK) (void)hipStreamSynchronize(st);   // nothing of a failed call may still be running on the workspace
     return rc;
 }

@@ -1322,6 +1322,7 @@ int gigl_scene_destroy(gigl_scene* s) {
     (void)hipFree(s->d_tris);
     (void)hipHostFree(s->h_one);
     (void)hipFree(s->one_ws);
+    (void)hipFree(s->photon_ws);
     if (s->one_stream) (void)hipStreamDestroy(s->one_stream);
     delete s;
     return GIGL_OK;
