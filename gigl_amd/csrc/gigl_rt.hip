@@ -400,6 +400,12 @@ __global__ void __launch_bounds__(BLOCK) GIGL_WAVES_ATTR trace_kernel(const Trac
                     if (rank < take) {
                         unsigned idx = pool_next + rank;
                         if (GEN == 0 && P.perm) idx = P.perm[idx];
+                        if ((GEN == 2 || GEN == 3) && P.n_pts) {
+                            // light-major order: the lanes of a wave hold neighbouring points and one light, so
+                            // their rays run side by side through the tree; results go to the pair's own bit
+                            const unsigned l = idx / P.n_pts;
+                            idx = (idx - l * P.n_pts) * P.n_lights + l;
+                        }
                         ray_idx = idx;
                         best_t = FLT_MAX; best_u = 0.0f; best_v = 0.0f; best_id = kMiss;
                         bool go = fetch_ray<GEN>(P, idx, r);
@@ -775,6 +781,9 @@ struct Options {
                               // a private block of triangle copies (kd_layout.h); 0 never; -1 the engine's choice:
                               // 2 when tree and triangle table exceed the 256 MB Infinity Cache anyway, else 6
                               // (only the big leaves: +14 % bytes on S(158), still cache resident, +1 %)
+    int shadow_order = 1;     // shadow-pair batches (generator 2): 1 trace the pairs light by light (neighbouring
+                              // points side by side in a wave: coherent rays), 0 in pair order (one point's lights
+                              // side by side); the output layout is the same
     int build_threads = 0;    // read at gigl_scene_create: host threads of the tree build (0: min(16, cores)); the
                               // tree does not depend on it
     int layout = 2;           // read at gigl_scene_create (kd_layout.h): 0 level treelets + separate id lists,
@@ -940,6 +949,10 @@ int launch_trace(const gigl_scene* s, TraceParams& P, hipStream_t st, const ExtW
         }
         P.perm = perm;
         if (ANY) P.any_atomic = 1;  // bits of regrouped rays are not consecutive: OR them in
+    }
+    if (GEN == 2 || GEN == 3) {
+        // light-major needs every lane to write its own bit (atomicOr mode) and both counts to fit the index maths
+        if (!(ANY && P.any_atomic && opt.shadow_order == 1 && P.n_lights > 1u)) P.n_pts = 0u;
     }
     P.refill_thresh = (ANY && !P.any_atomic) ? 64 : opt.refill_thresh;
     if (P.refill_thresh < 1) P.refill_thresh = 1;
@@ -1137,6 +1150,9 @@ int gigl_set_option(const char* name, int value) {
     } else if (k == "leaf_blocks") {
         if (value < -1 || value == 1 || value > 64) return fail(GIGL_ERR_INVALID, "leaf_blocks must be -1, 0 or 2..64");
         g_opt.leaf_blocks = value;
+    } else if (k == "shadow_order") {
+        if (value < 0 || value > 1) return fail(GIGL_ERR_INVALID, "shadow_order must be 0 or 1");
+        g_opt.shadow_order = value;
     } else if (k == "build_threads") {
         if (value < 0 || value > 256) return fail(GIGL_ERR_INVALID, "build_threads must be in 0..256");
         g_opt.build_threads = value;
@@ -1596,6 +1612,7 @@ static int shadow_batch(const gigl_scene* s, const void* prim_o_tmin, const void
     P.prim_hits = (const uint4*)prim_hits;
     P.lights = lights;
     P.n_lights = n_lights;
+    P.n_pts = (unsigned)n_pts;   // launch_trace keeps it only where the light-major order applies
     P.bits = (unsigned long long*)occluded_bits;
     if (occluded_bits && transm && fused) {   // visibility first, then the march of the visible pairs only
         int rc = launch_trace<true, 2>(s, P, (hipStream_t)stream);
@@ -1651,6 +1668,7 @@ int gigl_shadow_points_device(const gigl_scene* s, const float* points, uint64_t
     P.points = (const float4*)points;
     P.lights = lights;
     P.n_lights = n_lights;
+    P.n_pts = (unsigned)n_pts;
     P.bits = (unsigned long long*)occluded_bits;
     return launch_trace<true, 3>(s, P, (hipStream_t)stream);
 }

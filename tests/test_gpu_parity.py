@@ -430,6 +430,21 @@ def test_shadow_batch_cornell(gpu_cornell, oracle_cornell, cornell_cam, density,
     got_tr = tr.cpu().numpy().reshape(n_pts, nl)
     rel = np.abs(got_tr.astype(np.float64) - want_tr) / np.maximum(np.abs(want_tr), 1e-30)
     assert float(rel.max()) <= REL_TOL
+    # the order the pairs are traced in (light by light, the default, or pair order) and the any-hit output
+    # mode are scheduling choices: the bits land at the pair's own position either way
+    for order, any_atomic in ((0, -1), (1, 0), (0, 0), (1, 1)):
+        try:
+            rt.set_option("shadow_order", order)
+            rt.set_option("any_atomic", any_atomic)
+            bits.fill_(-1)
+            gpu_cornell.shadow_batch_device(d_o.data_ptr(), d_d.data_ptr(), d_h.data_ptr(), n_pts, d_l.data_ptr(), nl,
+                                            bits.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+        finally:
+            rt.set_option("shadow_order", 1)
+            rt.set_option("any_atomic", -1)
+        got2 = rt.unpack_bits(bits.cpu().numpy().view(np.uint64), n_pts * nl).reshape(n_pts, nl)
+        assert np.array_equal(got2, want01), (order, any_atomic)
     fog_g.close()
 
 
