@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--total-rays-log2", type=int, default=None,
                     help="rays over all GPUs = 2^this, contiguous shards (strong scaling; default 27 at N > 1)")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the RCCL gather of hit records")
+    ap.add_argument("--pipeline", type=int, default=-1,
+                    help="1: consecutive steps traverse on two alternating streams; 0: one stream; -1: on at N > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--extras", action="store_true", help="also time any-hit and the Cornell passes (N=1)")
     ap.add_argument("--sample-parity", dest="full_parity", action="store_false",
@@ -167,11 +169,15 @@ def main():
     stream = torch.cuda.current_stream()
     sh = stream.cuda_stream
 
-    def trace_fn(buf):
-        scene.trace_closest_device(d_o.data_ptr(), d_d.data_ptr(), n, buf.data_ptr(), sh)
+    def trace_fn(buf):   # on torch's current stream: the tracer decides which one that is
+        scene.trace_closest_device(d_o.data_ptr(), d_d.data_ptr(), n, buf.data_ptr(), torch.cuda.current_stream().cuda_stream)
 
+    # N > 1: consecutive steps traverse on two alternating streams (the drain of one launch is filled by the
+    # next one's first waves), as their gathers already overlap the next traversal.  N = 1 keeps one stream:
+    # the headline number is one launch after the other.
+    pipeline = (world > 1) if args.pipeline < 0 else bool(args.pipeline)
     tracer = shard.ShardedTracer(torch, dist if world > 1 else None, world, rank, n_total, device, trace_fn,
-                                 gather=not args.no_gather, backend=backend)
+                                 gather=not args.no_gather, backend=backend, pipeline=pipeline)
 
     def barrier():
         tracer.drain()
@@ -186,9 +192,7 @@ def main():
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     t_start = time.perf_counter()
     for i in range(args.steps):
-        ev0[i].record(stream)
-        tracer.step()
-        ev1[i].record(stream)
+        tracer.step(events=(ev0[i], ev1[i]))
     barrier()
     elapsed = time.perf_counter() - t_start
     kern_ms = [a.elapsed_time(b) for a, b in zip(ev0, ev1)]
@@ -198,6 +202,26 @@ def main():
         elapsed = float(tt.item())
     ms_per_step = elapsed * 1e3 / args.steps
     value = n_total * args.steps / elapsed / 1e6
+
+    # ---- N = 1, outside the timed region: the same steps with consecutive launches on two alternating streams
+    # (what a caller with a stream of batches gets; reported beside the headline, never as it) ----
+    piped = None
+    if world == 1 and not tracer.pipeline:
+        t2 = shard.ShardedTracer(torch, None, 1, 0, n_total, device, trace_fn, gather=False, pipeline=True)
+        for _ in range(2):
+            t2.step()
+        t2.drain()
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        for _ in range(args.steps):
+            t2.step()
+        t2.drain()
+        torch.cuda.synchronize()
+        tp = time.perf_counter() - tp
+        piped = {"value": round(n_total * args.steps / tp / 1e6, 3), "unit": "Mrays/s", "ms_per_step": round(tp * 1e3 / args.steps, 4),
+                 "what": "the same %d steps with consecutive launches on two alternating streams: the drain of one "
+                         "launch overlaps the start of the next" % args.steps}
+        del t2
 
     # ---- N > 1, not timed: the gathered records of every rank's range against a trace of the same rays
     # on rank 0's own GPU (first 2^16 rays of each range), and rank 0's rate on its shard with the other
@@ -296,8 +320,10 @@ def main():
             # 32 B ray in + 16 B hit out + 8 B per node visited + 56 B per triangle test
             bytes_per_ray = 32.0 + 16.0 + 8.0 * mean_nodes + 56.0 * mean_tris
         k_ms = float(np.mean(kern_ms))
-        # per GPU: one launch over this rank's rays
-        achieved = bytes_per_ray * n / (k_ms * 1e-3) / 1e9 if bytes_per_ray is not None else None
+        # per GPU: one launch over this rank's rays.  Pipelined steps overlap on two streams, so an event pair
+        # around one launch also spans part of its neighbours: the per-launch time is then the step time.
+        k_eff_ms = ms_per_step if tracer.pipeline else k_ms
+        achieved = bytes_per_ray * n / (k_eff_ms * 1e-3) / 1e9 if bytes_per_ray is not None else None
         traffic, traffic_src = traffic_from_profiles("bounce" if tess == 158 else "bounce_s%d" % tess, layout, n)
         per_cu, n_cus = scene.launch_info()
         out = {
@@ -315,12 +341,15 @@ def main():
                        "triangles": int(len(T)), "rays_total": int(n_total), "rays_rank0": int(n),
                        "tree_build_ms": round(st.build_ms, 1), "tree_device_bytes": int(st.device_bytes),
                        "device_layout": layout, "setup_s": round(setup_s, 1),
-                       "same_scene_one_gpu": alone, "gather_check": gather_check, "commit": git_head()},
+                       "same_scene_one_gpu": alone, "gather_check": gather_check,
+                       "pipelined_two_streams": piped, "commit": git_head()},
             "roofline": {"bound": "hbm", "achieved": None if achieved is None else round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": kernel_name(layout), "kernel_ms": round(k_ms, 4),
+                         "kernel": kernel_name(layout), "kernel_ms": round(k_eff_ms, 4),
+                         "pipelined": tracer.pipeline,
+                         "kernel_ms_events": round(k_ms, 4),
                          "waves_per_simd": per_cu, "workgroups": per_cu * n_cus,
                          "algorithmic_bytes_per_ray": None if bytes_per_ray is None else round(bytes_per_ray, 2),
                          "mean_nodes_visited": mean_nodes, "mean_triangle_tests": mean_tris,

@@ -5,7 +5,9 @@ rank r traces the contiguous ray range shard_range(n, world, r), and the only ex
 gather of the hit buffers to rank 0 (16 B per closest-hit ray).  ShardedTracer is that step, used
 as it stands by bench.py (RCCL, one rank per GPU) and by tests/test_multi_rank_gloo.py (gloo, CPU
 tensors, a stand-in tracer): step i's gather runs behind step i+1's traversal (two hit buffers, a
-second stream), one traversal launch per step.
+second stream), one traversal launch per step.  With pipeline=True consecutive steps also traverse on
+two alternating streams, so the drain at the end of one step's launch (the last long rays, with most of
+the chip idle) is filled by the next step's first waves.
 """
 
 
@@ -28,9 +30,13 @@ class ShardedTracer:
     On a GPU with the nccl (= RCCL) backend the gather of step i is issued on a second stream behind
     an event and overlaps the traversal of step i + 1; every other combination (CPU tensors, or GPU
     tensors with gloo: through host memory) gathers synchronously.
+    pipeline=True (GPU only): step i runs on traversal stream i % 2, under which trace_fn is called (it must
+    launch on torch's current stream).  gather_when_alone=True keeps the gather at world == 1 (a loopback
+    that exercises the RCCL branch on one GPU).
     """
 
-    def __init__(self, torch, dist, world, rank, n_total, device, trace_fn, gather=True, backend="nccl"):
+    def __init__(self, torch, dist, world, rank, n_total, device, trace_fn, gather=True, backend="nccl",
+                 pipeline=False, gather_when_alone=False):
         self.torch, self.dist, self.world, self.rank = torch, dist, world, rank
         self.n_total = int(n_total)
         self.device = torch.device(device)
@@ -39,11 +45,13 @@ class ShardedTracer:
         self.lo, self.hi = self.ranges[rank]
         self.m = self.hi - self.lo
         self.m_max = max(hi - lo for lo, hi in self.ranges)      # the collective wants equal sizes
-        self.gather = bool(gather) and world > 1
+        self.gather = bool(gather) and (world > 1 or (gather_when_alone and dist is not None))
         self.on_gpu = self.device.type == "cuda"
         self.overlap = self.gather and self.on_gpu and backend == "nccl"
+        self.pipeline = bool(pipeline) and self.on_gpu
         new = lambda: torch.zeros((self.m_max, 4), dtype=torch.int32, device=self.device)
-        self.bufs = [new(), new()] if self.gather else [new()]
+        self.bufs = [new(), new()] if (self.gather or self.pipeline) else [new()]
+        self.trav_streams = [torch.cuda.Stream(device=self.device) for _ in range(2)] if self.pipeline else None
         self.gathered = None
         if self.gather and rank == 0:
             gdev = self.device if (self.overlap or not self.on_gpu) else torch.device("cpu")
@@ -52,18 +60,40 @@ class ShardedTracer:
         self.pending = {}
         self.i = 0
 
-    def step(self):
+    def step_stream(self, i=None):
+        """The stream step i (default: the next one) traverses on; None on the CPU."""
+        if not self.on_gpu:
+            return None
+        i = self.i if i is None else i
+        return self.trav_streams[i % 2] if self.pipeline else self.torch.cuda.current_stream(self.device)
+
+    def step(self, events=None):
+        """One step.  events: optional (start, end) torch.cuda.Event pair recorded around the traversal on
+        the stream it runs on."""
+        if self.pipeline:
+            if self.i < 2:   # the first launch on each traversal stream follows whatever the caller queued before
+                self.trav_streams[self.i % 2].wait_stream(self.torch.cuda.current_stream(self.device))
+            with self.torch.cuda.stream(self.trav_streams[self.i % 2]):
+                self._step(events)
+        else:
+            self._step(events)
+
+    def _step(self, events):
         torch, dist = self.torch, self.dist
         i = self.i
         self.i += 1
         buf = self.bufs[i % len(self.bufs)]
         if (i - 2) in self.pending:
             self.pending.pop(i - 2).wait()      # the gather that last read this buffer (stream-level wait on a GPU)
+        stream = torch.cuda.current_stream(self.device) if self.on_gpu else None
+        if events:
+            events[0].record(stream)
         self.trace_fn(buf)
+        if events:
+            events[1].record(stream)
         if not self.gather:
             return
         if self.overlap:
-            stream = torch.cuda.current_stream(self.device)
             ev = torch.cuda.Event()
             ev.record(stream)
             with torch.cuda.stream(self.comm_stream):
@@ -74,11 +104,16 @@ class ShardedTracer:
             dist.gather(src, self.gathered if self.rank == 0 else None, dst=0)
 
     def drain(self):
-        """Completes every gather issued so far (and orders the current stream behind them)."""
+        """Completes every traversal and gather issued so far (and orders the current stream behind them)."""
         for k in sorted(self.pending):
             self.pending.pop(k).wait()
-        if self.overlap:
-            self.torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
+        if self.on_gpu:
+            cur = self.torch.cuda.current_stream(self.device)
+            if self.overlap:
+                cur.wait_stream(self.comm_stream)
+            if self.pipeline:
+                for t in self.trav_streams:
+                    cur.wait_stream(t)
 
     def local_hits(self):
         """This rank's records of the last step, [m, 4]."""
