@@ -192,6 +192,15 @@ public:
     float sampleScaK(vec3 pos) const { return m_sca_k * sampleDensity(pos); }              // :38-41
     float getMajExtK() const { return m_maj_ext_k; }
     float getScaAlbedo() const { return m_sca_k / (m_abs_k + m_sca_k); }                   // :43-46
+    // rt::PhotonTracer::trace as ray batches on the device (gigl_photon_trace_batch, substream mode): the
+    // whole VPL set of one primary light in one call; la receives normalised, renumbered records.
+    void tracePhotonsBatch(vec3 source_pos, vec3 source_intensity, vec3 shoot_dir, int max_vpl_count, uint64_t seed,
+                           std::vector<uint8_t>& vpl_bytes, int& n_vpls, uint32_t& n_paths) const {
+        vpl_bytes.assign((size_t)max_vpl_count * 96, 0);
+        check(gigl_photon_trace_batch(m_scene, m_fog, &m_materials[0].k_d.x, (uint32_t)m_materials.size(), m_abs_k,
+                                      m_sca_k, m_maj_ext_k, m_fog_enabled ? 1 : 0, &source_pos.x, &source_intensity.x,
+                                      &shoot_dir.x, max_vpl_count, seed, 0, vpl_bytes.data(), &n_vpls, &n_paths));
+    }
     vec3 boxMin() const { return m_box_min; }
     vec3 boxMax() const { return m_box_max; }
     bool fogEnabled() const { return m_fog_enabled; }
@@ -229,6 +238,19 @@ inline vec3 genVecSinCos(float phi, float sin_the, float cos_the) {  // RTBase.h
 
 // rt::PhotonTracer::trace, Source/RT/PhotonTracer.cpp:78-188.  `rng` replaces UnitRNG::generate.
 struct PhotonTracer {
+    // The same set as ray batches on the device, each path drawing from its own substream of `seed`
+    // (include/gigl_rt.h: gigl_photon_trace_batch).  Replaces the call at Source/Common/Renderer.cpp:223.
+    static void traceBatch(const Scene& scene, vec3 source_pos, vec3 source_intensity, vec3 shoot_dir,
+                           int max_vpl_count, LightArray& la, uint64_t seed, uint32_t* n_paths_out = nullptr) {
+        la.clear();
+        std::vector<uint8_t> bytes;
+        int n = 0;
+        uint32_t n_paths = 0;
+        scene.tracePhotonsBatch(source_pos, source_intensity, shoot_dir, max_vpl_count, seed, bytes, n, n_paths);
+        la.pls.resize((size_t)n);
+        if (n) std::memcpy(la.pls.data(), bytes.data(), (size_t)n * sizeof(VPL));
+        if (n_paths_out) *n_paths_out = n_paths;
+    }
     static void trace(const Scene& scene, vec3 source_pos, vec3 source_intensity, vec3 /*shoot_dir*/,
                       int max_vpl_count, LightArray& la, const std::function<float()>& rng,
                       uint32_t* n_paths_out = nullptr) {
