@@ -243,7 +243,23 @@ __global__ void __launch_bounds__(BLOCK) GIGL_WAVES_ATTR trace_kernel(const Trac
     const unsigned lane = tid & 63u;
     for (int i = (int)tid; i < kEpsTable; i += BLOCK) s_eps[i] = eps_from_exp(i - kEpsBias + 1);
     __syncthreads();
+#if GIGL_EPS_ALU
+    // For frexp exponents in [-31, 29] (|t| in [2^-32, 2^29), and 0/inf/NaN, whose exponent reads 0) the
+    // reference's value is 2^(e - 23) whichever branch of RTBase.h:24-28 it takes: assembled in two
+    // instructions, off the LDS round trip; the wrap-around cases beyond that range read the table.
+    auto eps_of = [&](float t) {
+        const int fe = __builtin_amdgcn_frexp_expf(t);
+        float v = __uint_as_float((unsigned)(fe + 105) << 23);
+        const bool odd = (unsigned)(fe + 31) > 60u;
+        if (__ballot(odd) != 0ull) {
+            asm volatile("" ::: "memory");
+            if (odd) v = s_eps[(unsigned)(fe + kEpsBias)];
+        }
+        return v;
+    };
+#else
     auto eps_of = [&](float t) { return s_eps[(unsigned)(__builtin_amdgcn_frexp_expf(t) + kEpsBias)]; };
+#endif
     uint2* const my_stack = s_stack + tid;
     unsigned* const my_stack0 = s_stack0 + tid;
     uint4* const my_spill = P.spill + ((size_t)blockIdx.x * BLOCK + tid);
