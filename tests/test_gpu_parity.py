@@ -140,7 +140,7 @@ def test_launch_options_do_not_change_results(s16, stack_lds, refill, any_atomic
         rt.set_option("sort_rays", 0)
         rt.set_option("sort_bits", 6)
         rt.set_option("guided", 4)
-        rt.set_option("chunk", 256)
+        rt.set_option("chunk", 0)
 
 
 @pytest.mark.parametrize("layout", [0, 1, 2])
