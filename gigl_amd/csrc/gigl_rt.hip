@@ -504,6 +504,8 @@ __global__ void __launch_bounds__(BLOCK) GIGL_WAVES_ATTR trace_kernel(const Trac
                 if (lvl == 1u) {   // a leaf inside a record: its payload names the prims
                     const unsigned payload = rec.x, kind = payload & 3u;
                     if (kind == 2u) rec = recs[payload >> 2];
+                    else if (kind == 3u)   // a triangle block named by the payload (kd_layout.h): no leaf record to fetch
+                        rec = make_uint4(payload >> 7, 0u, 0u, 3u | (((payload >> 2) & 31u) << 2) | gigl::kLeafBlockFlag);
                     else rec = make_uint4(payload >> 2, 0u, 0u, kind == 1u ? (3u | (1u << 2)) : 3u);
                     lvl = 0u;
                 }

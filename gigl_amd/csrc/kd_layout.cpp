@@ -339,6 +339,13 @@ bool layout_triples(const KdTreeHost& T, DeviceTree& dt) {
         const uint32_t n = n_of(k);
         if (n == 0u) return 0u;
         if (n == 1u) { if (H[k].w0 >= (1u << 30)) ok = false; return (H[k].w0 << 2) | 1u; }
+        if (in_block(k) && n <= kPayloadBlockMaxN && dt.block_ids.size() / 3u < (1u << kPayloadBlockLineBits)) {
+            // the block is named by the payload itself: no leaf record, one dependent load less
+            const uint32_t first_line = (uint32_t)(dt.block_ids.size() / 3u);
+            for (uint32_t i = 0; i < n; ++i) dt.block_ids.push_back(id_of(k, i));
+            while (dt.block_ids.size() % 3u) dt.block_ids.push_back(kLeafBlockPad);
+            return (first_line << 7) | (n << 2) | 3u;
+        }
         const uint32_t u = alloc_aux(1);
         if (u >= (1u << 30)) ok = false;
         write_leaf_record(u, k);
@@ -378,7 +385,7 @@ bool layout_triples(const KdTreeHost& T, DeviceTree& dt) {
         uint32_t a = 0;
         const uint32_t kids[2] = {g + 1u, H[g].w1 >> 3};
         for (uint32_t c : kids)
-            if (is_leaf(H[c]) && n_of(c) >= 2u) a += 1u + arr_units(c);
+            if (is_leaf(H[c]) && n_of(c) >= 2u && !(in_block(c) && n_of(c) <= kPayloadBlockMaxN)) a += 1u + arr_units(c);
         return a;
     };
     auto block_of = [&](uint32_t k, uint32_t g[4]) -> uint32_t {   // the grandchildren of interior node k
@@ -536,8 +543,15 @@ bool verify_triples(const KdTreeHost& T, const DeviceTree& D, const char** what)
             if (is_leaf(c)) {
                 if (type != 3u) return bad("child leaf type");
                 const uint32_t n = c.w1 >> 1, kind = slot & 3u;
-                if (n == 0u ? slot != 0u : n == 1u ? (kind != 1u || (slot >> 2) != c.w0)
-                                                   : (kind != 2u || !leaf_record_ok(slot >> 2, kids[j])))
+                if (kind == 3u) {   // a triangle block named by the payload
+                    const size_t first = (size_t)(slot >> 7) * 3u;
+                    if (D.leaf_block_min == 0u || n < D.leaf_block_min || n > kPayloadBlockMaxN || ((slot >> 2) & 31u) != n ||
+                        first + n > D.block_ids.size())
+                        return bad("child leaf block payload");
+                    for (uint32_t i = 0; i < n; ++i) if (D.block_ids[first + i] != id_of(kids[j], i)) return bad("child leaf block ids");
+                    for (size_t i = first + n; i % 3u; ++i) if (D.block_ids[i] != kLeafBlockPad) return bad("child leaf block padding");
+                } else if (n == 0u ? slot != 0u : n == 1u ? (kind != 1u || (slot >> 2) != c.w0)
+                                                          : (kind != 2u || !leaf_record_ok(slot >> 2, kids[j])))
                     return bad("child leaf payload");
             } else {
                 if (type != ((c.w1 >> 1) & 3u)) return bad("child axis");

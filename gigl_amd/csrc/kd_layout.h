@@ -31,6 +31,8 @@ constexpr uint32_t kDevLeafBit = 0x80000000u, kDevLeafPayload = 0x1FFFFFFFu;
 //     interior) followed by those of B's children (if B is interior)
 //   leaf payload in a slot: kind (bits 0-1) 0 empty | 1 one prim, id = payload >> 2
 //                           | 2 list, leaf record unit = payload >> 2
+//                           | 3 triangle block named by the payload itself (leaf_block_min <= n <= 31):
+//                             n = bits 2-6, first 128-byte line of the block = payload >> 7 (no leaf record)
 //   leaf record (a leaf at an even depth, or the list of a child-position leaf):
 //     w = 3 | n << 2;  n <= 3: x, y, z = ids;  n > 3: x = unit index of the id array (dwords,
 //     padded to an even count, read 8 bytes at a time)
@@ -42,6 +44,7 @@ constexpr uint32_t kDevLeafBit = 0x80000000u, kDevLeafPayload = 0x1FFFFFFFu;
 // One 16-byte load serves two levels of the descent.
 constexpr uint32_t kTriplePtrBits = 26;
 constexpr uint32_t kLeafBlockFlag = 0x80000000u, kLeafBlockPad = 0xFFFFFFFFu;
+constexpr uint32_t kPayloadBlockMaxN = 31, kPayloadBlockLineBits = 25;
 
 struct DeviceTree {
     std::vector<KdNode> slots;          // 8-byte slots: nodes (and, clustered layout, inline id lists)
