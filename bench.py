@@ -203,10 +203,10 @@ def main():
     ms_per_step = elapsed * 1e3 / args.steps
     value = n_total * args.steps / elapsed / 1e6
 
-    # ---- N = 1, outside the timed region: the same steps with consecutive launches on two alternating streams
+    # ---- N = 1, --extras, outside the timed region: the same steps with consecutive launches on two alternating streams
     # (what a caller with a stream of batches gets; reported beside the headline, never as it) ----
     piped = None
-    if world == 1 and not tracer.pipeline:
+    if world == 1 and not tracer.pipeline and args.extras:   # not by default: its overlapping launches would blur a profile of this command
         t2 = shard.ShardedTracer(torch, None, 1, 0, n_total, device, trace_fn, gather=False, pipeline=True)
         for _ in range(2):
             t2.step()
