@@ -109,6 +109,16 @@ int gigl_fog_create(const uint8_t* dens, const int res[3], const float box[6], f
     }
     f->fp = FogParams{f->d_bricks, res[0], res[1], res[2], box[0], box[1], box[2], box[3], box[4], box[5], ext_k,
                       n_intervals};
+    // optional fast path of gigl_sample_density: without it the call falls back to plain copies
+    if (hipHostMalloc((void**)&f->h_stage, 4 * gigl_fog::kStagePositions * sizeof(float), hipHostMallocMapped) == hipSuccess &&
+        hipHostGetDevicePointer((void**)&f->d_stage, f->h_stage, 0) == hipSuccess &&
+        hipStreamCreateWithFlags(&f->stage_stream, hipStreamNonBlocking) == hipSuccess) {
+    } else {
+        if (f->h_stage) (void)hipHostFree(f->h_stage);
+        f->h_stage = f->d_stage = nullptr;
+        f->stage_stream = nullptr;
+        (void)hipGetLastError();
+    }
     *out = f;
     return GIGL_OK;
 }
@@ -118,6 +128,8 @@ int gigl_fog_destroy(gigl_fog* f) {
     DeviceGuard g(f->device);
     (void)hipDeviceSynchronize();
     (void)hipFree(f->d_bricks);
+    if (f->h_stage) (void)hipHostFree(f->h_stage);
+    if (f->stage_stream) (void)hipStreamDestroy(f->stage_stream);
     delete f;
     return GIGL_OK;
 }
@@ -164,6 +176,18 @@ int gigl_sample_density(const gigl_fog* f, const float* pos, uint64_t n, float* 
     if (n == 0) return GIGL_OK;
     if (!pos || !dens_out) return fail(GIGL_ERR_INVALID, "NULL pointer");
     if (n > (1u << 28)) return fail(GIGL_ERR_TOO_LARGE, "at most 2^28 positions per call");
+    if (n <= gigl_fog::kStagePositions && f->h_stage && f->stage_stream) {
+        gigl_fog* mf = const_cast<gigl_fog*>(f);
+        std::lock_guard<std::mutex> lk(mf->stage_mu);
+        DeviceGuard g(f->device);
+        memcpy(f->h_stage, pos, 3 * (size_t)n * sizeof(float));
+        hipLaunchKernelGGL(sample_density_kernel, dim3(1), dim3(256), 0, f->stage_stream, f->fp, (const float*)f->d_stage,
+                           (unsigned)n, f->d_stage + 3 * gigl_fog::kStagePositions);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(f->stage_stream));
+        memcpy(dens_out, f->h_stage + 3 * gigl_fog::kStagePositions, (size_t)n * sizeof(float));
+        return GIGL_OK;
+    }
     return map_host(f->device, pos, 3 * n, n, dens_out,
                     [](const float* in, unsigned m, float* o, const void* ctx) {
                         hipLaunchKernelGGL(sample_density_kernel, dim3((m + 255) / 256), dim3(256), 0, nullptr,

@@ -309,6 +309,13 @@ struct gigl_fog {
     int device = 0;
     uint2* d_bricks = nullptr;
     gd::FogParams fp;
+    // gigl_sample_density on a few positions (the serial photon walk samples one at a time): pinned,
+    // device-mapped staging and a stream of its own, so a call is one launch and one synchronisation
+    static constexpr unsigned kStagePositions = 64;
+    float* h_stage = nullptr;      // 3 * kStagePositions floats in, kStagePositions floats out
+    float* d_stage = nullptr;
+    hipStream_t stage_stream = nullptr;
+    std::mutex stage_mu;
 };
 
 namespace gd {

@@ -1,0 +1,17 @@
+import os, subprocess, sys, numpy as np
+sys.path.insert(0, "/root/repo")
+from gigl_amd import scene_io as S
+from oracle import oracle_py as O
+ROOT="/root/repo"
+v,t,m,_=S.load_obj(ROOT+"/tests/golden/cornell_box.obj")
+dens=O.make_density((64,64,64),12.0,1.0)
+rng=np.random.default_rng(20261110).random(100000, dtype=np.float32)
+inp="/tmp/plumb_in.bin"
+with open(inp,"wb") as f:
+    f.write(np.array([len(v),len(t),len(m),len(rng),S.MAX_N_VPLS],np.uint32).tobytes())
+    for a in (v,t,m,dens,rng,np.array(S.PRIM_PL_POS,np.float32),np.array(S.PRIM_PL_INTENS,np.float32),np.array([S.MAJ_EXT_K,S.ABS_K,S.SCA_K],np.float32)):
+        f.write(np.ascontiguousarray(a).tobytes())
+for extra in ([],["7"]):
+    for rep in range(2):
+        r=subprocess.run([ROOT+"/tests/cpp/vpl_plumbing",inp,"/tmp/plumb_out.bin","1"]+extra,capture_output=True,text=True)
+        print(r.stdout.strip(), r.stderr.strip()[-200:])
