@@ -1,8 +1,10 @@
+"""Times the C++ host program tests/cpp/vpl_plumbing on the golden 150-VPL set: the serial walk (one launch per
+query) and the same set as ray batches (GPU box)."""
 import os, subprocess, sys, numpy as np
-sys.path.insert(0, "/root/repo")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 from gigl_amd import scene_io as S
 from oracle import oracle_py as O
-ROOT="/root/repo"
 v,t,m,_=S.load_obj(ROOT+"/tests/golden/cornell_box.obj")
 dens=O.make_density((64,64,64),12.0,1.0)
 rng=np.random.default_rng(20261110).random(100000, dtype=np.float32)
