@@ -282,7 +282,7 @@ struct gigl_scene {
     uint2* d_nodes = nullptr;
     uint2 root = {0u, 0x80000000u};
     uint4 root_rec = {0u, 0u, 0u, 3u};
-    bool triples = false;          // d_nodes holds the triple layout (trace3_kernel)
+    bool triples = false;          // d_nodes holds the triple layout (trace_kernel<TRIPLES = true>)
     unsigned* d_leaf_ids = nullptr;
     float4* d_tris = nullptr;
     unsigned blocks_off8 = 0;      // leaf triangle blocks (kd_layout.h) start here in d_tris, in 8-byte units (0: none)

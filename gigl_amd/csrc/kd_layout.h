@@ -4,7 +4,7 @@
 // (/root/reference/Source/RT/KdTree.h:22-65, KdTree.hpp:254-262).  The traversal kernel reads a
 // re-addressed copy: same topology, same leaf contents in the same order, different addresses.
 // Three layouts are provided.  The level and clustered layouts use the pair-addressed node encoding
-// read by trace_kernel (the triple layout, read by trace3_kernel, is described further down):
+// read by trace_kernel<TRIPLES = false> (the triple layout, TRIPLES = true, is described further down):
 //   interior: w0 = split_pos, w1 = slot of the children pair << 2 | axis (bottom child first)
 //   leaf:     w1 bit 31 = 1, bits 29-30 = kind, bits 0-28 = payload
 //             kind 0 empty | 1 one prim (w0 = id) | 2 two prims (w0 = id0, payload = id1)

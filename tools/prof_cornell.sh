@@ -1,4 +1,4 @@
-# Counters of the Cornell shadow-batch kernel (trace3_kernel<true, 2, ...>) under bench.py --extras (gpurun box).
+# Counters of the Cornell shadow-batch kernel (trace_kernel<triples, any-hit, generator 2>) under bench.py --extras (gpurun box).
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 timeout -s KILL 280 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVES SQ_BUSY_CYCLES --output-format csv -d $R/gpurun_out/cornell/sq -- python3 $R/bench.py --no-cpu-baseline --steps 1 --warmup 1 --extras > $R/gpurun_out/cornell_sq.log 2>&1 || exit 1
