@@ -228,6 +228,7 @@ struct TraceParams {
     const uint4* prim_hits;
     const float* lights;
     unsigned n_lights;
+    const float4* pt_cache;  // optional: per point (p, valid), (shadow-ray origin, -) from shadow_points_kernel
     unsigned n_pts;          // light-major order: work item i is pair (i % n_pts) * n_lights + i / n_pts; 0: pair order
     // GEN 3: (point, light) pairs from explicit points (x, y, z, valid)
     const float4* points;

@@ -31,17 +31,18 @@ using namespace gd;
 
 namespace {
 
-struct ShadowSeg { float px, py, pz, wx, wy, wz, dist_sq, dist; float nx, ny, nz; };
+struct ShadowSeg { float px, py, pz, wx, wy, wz, dist_sq, dist; float ox, oy, oz; };
 
-// Shadow-ray construction (DESIGN.md "Shadow batch"): p = o + t*d; N = normalize(cross(e0,e1))
-// turned to face the primary ray; w = normalize(L - p); range (0, |L - p|).
-__device__ __forceinline__ bool shadow_segment(const TraceParams& P, unsigned pair, ShadowSeg& s) {
-    const unsigned pt = pair / P.n_lights, l = pair - pt * P.n_lights;
+// Per-point half of the shadow-ray construction (DESIGN.md "Shadow batch"): p = o + t*d; N =
+// normalize(cross(e0,e1)) turned to face the primary ray; origin of the shadow rays = p + RAY_OFFSET * N.
+// valid = 0 where the primary ray missed.
+__device__ __forceinline__ bool shadow_point(const TraceParams& P, unsigned pt, float& px, float& py, float& pz,
+                                             float& ox, float& oy, float& oz) {
     const uint4 h = P.prim_hits[pt];
     if (h.x == kMiss) return false;
     const float4 o = P.prim_o[pt], d = P.prim_d[pt];
     const float t = __uint_as_float(h.y);
-    s.px = o.x + t * d.x; s.py = o.y + t * d.y; s.pz = o.z + t * d.z;  // getPtAtDist, RTBase.cpp:124-126
+    px = o.x + t * d.x; py = o.y + t * d.y; pz = o.z + t * d.z;  // getPtAtDist, RTBase.cpp:124-126
     const float4 a = P.tris[kTriStride * (size_t)h.x], b = P.tris[kTriStride * (size_t)h.x + 1];
     const float e1z = P.tris[kTriStride * (size_t)h.x + 2].x;
     const float e0x = a.w, e0y = b.x, e0z = b.y, e1x = b.z, e1y = b.w;
@@ -49,13 +50,30 @@ __device__ __forceinline__ bool shadow_segment(const TraceParams& P, unsigned pa
     const float inv = 1.0f / sqrtf(nx * nx + ny * ny + nz * nz);
     nx = nx * inv; ny = ny * inv; nz = nz * inv;
     if ((d.x * nx + d.y * ny) + d.z * nz > 0.0f) { nx = -nx; ny = -ny; nz = -nz; }
-    s.nx = nx; s.ny = ny; s.nz = nz;
+    ox = px + kRayOffset * nx; oy = py + kRayOffset * ny; oz = pz + kRayOffset * nz;   // Ray{p, w, N}, RTBase.cpp:117-122
+    return true;
+}
+
+// The (point, light) pair: w = normalize(L - p); range (0, |L - p|).  With P.pt_cache the per-point half
+// comes from the two float4 a pre-pass stored per point (the same values: it ran shadow_point once per
+// point instead of once per pair).
+__device__ __forceinline__ bool shadow_segment(const TraceParams& P, unsigned pt, unsigned l, ShadowSeg& s) {
+    if (P.pt_cache) {
+        const float4 a = P.pt_cache[2 * (size_t)pt];
+        if (!(a.w > 0.0f)) return false;
+        const float4 b = P.pt_cache[2 * (size_t)pt + 1];
+        s.px = a.x; s.py = a.y; s.pz = a.z; s.ox = b.x; s.oy = b.y; s.oz = b.z;
+    } else if (!shadow_point(P, pt, s.px, s.py, s.pz, s.ox, s.oy, s.oz)) return false;
     const float vx = P.lights[3 * l] - s.px, vy = P.lights[3 * l + 1] - s.py, vz = P.lights[3 * l + 2] - s.pz;
     s.dist_sq = (vx * vx + vy * vy) + vz * vz;
     s.dist = sqrtf(s.dist_sq);
     const float iv = 1.0f / sqrtf(s.dist_sq);
     s.wx = vx * iv; s.wy = vy * iv; s.wz = vz * iv;
     return true;
+}
+__device__ __forceinline__ bool shadow_segment(const TraceParams& P, unsigned pair, ShadowSeg& s) {
+    const unsigned pt = pair / P.n_lights;
+    return shadow_segment(P, pt, pair - pt * P.n_lights, s);
 }
 
 // Rays and hit records are touched once: streamed with the nontemporal hint so that they do not
@@ -79,8 +97,9 @@ __device__ __forceinline__ void stream_store(uint4* p, uint4 v) {
 #endif
 }
 
+// idx: the ray (GEN 0), the pixel (GEN 1) or the point of a (point, light) pair (GEN 2, 3; l = its light)
 template <int GEN>
-__device__ __forceinline__ bool fetch_ray(const TraceParams& P, unsigned idx, RayReg& r) {
+__device__ __forceinline__ bool fetch_ray(const TraceParams& P, unsigned idx, unsigned l, RayReg& r) {
     if (GEN == 0) {
         const float4 o = stream_load(P.o_tmin + idx), d = stream_load(P.d_tmax + idx);
         r.ox = o.x; r.oy = o.y; r.oz = o.z;
@@ -96,16 +115,15 @@ __device__ __forceinline__ bool fetch_ray(const TraceParams& P, unsigned idx, Ra
         return true;
     } else if (GEN == 2) {
         ShadowSeg s;
-        if (!shadow_segment(P, idx, s)) return false;
-        r.ox = s.px + kRayOffset * s.nx; r.oy = s.py + kRayOffset * s.ny; r.oz = s.pz + kRayOffset * s.nz;
+        if (!shadow_segment(P, idx, l, s)) return false;
+        r.ox = s.ox; r.oy = s.oy; r.oz = s.oz;
         set_dir(r, s.wx, s.wy, s.wz);
         r.tmin = 0.0f; r.tmax = s.dist;
         return true;
     } else {
         // visibility of light l from a point in the volume: Ray{p, normalize(L - p)} (no normal,
         // so no origin offset), range (0, |L - p|)
-        const unsigned pt = idx / P.n_lights, l = idx - pt * P.n_lights;
-        const float4 p = P.points[pt];
+        const float4 p = P.points[idx];
         if (!(p.w > 0.0f)) return false;
         const float vx = P.lights[3 * l] - p.x, vy = P.lights[3 * l + 1] - p.y, vz = P.lights[3 * l + 2] - p.z;
         const float dist_sq = (vx * vx + vy * vy) + vz * vz;
@@ -416,15 +434,22 @@ __global__ void __launch_bounds__(BLOCK) GIGL_WAVES_ATTR trace_kernel(const Trac
                     if (rank < take) {
                         unsigned idx = pool_next + rank;
                         if (GEN == 0 && P.perm) idx = P.perm[idx];
-                        if ((GEN == 2 || GEN == 3) && P.n_pts) {
-                            // light-major order: the lanes of a wave hold neighbouring points and one light, so
-                            // their rays run side by side through the tree; results go to the pair's own bit
-                            const unsigned l = idx / P.n_pts;
-                            idx = (idx - l * P.n_pts) * P.n_lights + l;
+                        unsigned src = idx, light = 0u;   // what fetch_ray reads: the ray / pixel, or (point, light)
+                        if (GEN == 2 || GEN == 3) {
+                            if (P.n_pts) {
+                                // light-major order: the lanes of a wave hold neighbouring points and one light, so
+                                // their rays run side by side through the tree; results go to the pair's own bit
+                                light = idx / P.n_pts;
+                                src = idx - light * P.n_pts;
+                                idx = src * P.n_lights + light;
+                            } else {
+                                src = idx / P.n_lights;
+                                light = idx - src * P.n_lights;
+                            }
                         }
                         ray_idx = idx;
                         best_t = FLT_MAX; best_u = 0.0f; best_v = 0.0f; best_id = kMiss;
-                        bool go = fetch_ray<GEN>(P, idx, r);
+                        bool go = fetch_ray<GEN>(P, src, light, r);
                         if (go) {
                             // KdTree.hpp:269-274
                             float entr, exit;
@@ -705,6 +730,17 @@ __global__ void __launch_bounds__(256) primary_rays_kernel(const Cam12 cam, unsi
         primary_ray(cam.c, res_x, first + i, dx, dy, dz);
         o_tmin[i] = make_float4(cam.c[0], cam.c[1], cam.c[2], 0.0f);
         d_tmax[i] = make_float4(dx, dy, dz, FLT_MAX);
+    }
+}
+
+// The per-point half of every shadow pair, once per point instead of once per pair (150 lights per point
+// in configs[1]): hit point, facing normal, offset origin.  Same operations, same results.
+__global__ void __launch_bounds__(256) shadow_points_kernel(TraceParams P, unsigned n_pts, float4* cache) {
+    for (unsigned pt = blockIdx.x * 256u + threadIdx.x; pt < n_pts; pt += gridDim.x * 256u) {
+        float px = 0.0f, py = 0.0f, pz = 0.0f, ox = 0.0f, oy = 0.0f, oz = 0.0f;
+        const bool ok = shadow_point(P, pt, px, py, pz, ox, oy, oz);
+        cache[2 * (size_t)pt] = make_float4(px, py, pz, ok ? 1.0f : 0.0f);
+        cache[2 * (size_t)pt + 1] = make_float4(ox, oy, oz, 0.0f);
     }
 }
 
@@ -1633,6 +1669,19 @@ static int shadow_batch(const gigl_scene* s, const void* prim_o_tmin, const void
     P.n_lights = n_lights;
     P.n_pts = (unsigned)n_pts;   // launch_trace keeps it only where the light-major order applies
     P.bits = (unsigned long long*)occluded_bits;
+    P.tris = s->d_tris;
+    // the per-point half of the pairs, computed once per point (worth it from a few lights per point on)
+    void* cache = nullptr;
+    if (n_lights >= 4u) {
+        HIP_TRY(hipMallocAsync(&cache, (size_t)n_pts * 2 * sizeof(float4), (hipStream_t)stream));
+        hipLaunchKernelGGL(shadow_points_kernel, dim3(stream_grid(s, n_pts)), dim3(256), 0, (hipStream_t)stream, P,
+                           (unsigned)n_pts, (float4*)cache);
+        P.pt_cache = (const float4*)cache;
+    }
+    struct FreeCache {   // released in stream order behind the launches that read it
+        void* p; hipStream_t st;
+        ~FreeCache() { if (p) (void)hipFreeAsync(p, st); }
+    } free_cache{cache, (hipStream_t)stream};
     if (occluded_bits && transm && fused) {   // visibility first, then the march of the visible pairs only
         int rc = launch_trace<true, 2>(s, P, (hipStream_t)stream);
         if (rc != GIGL_OK) return rc;
