@@ -37,6 +37,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 L2_PEAK_GBS = 34500.0   # same guide: aggregate L2 bandwidth, ~34.5 TB/s
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 4.0   # G wave-instructions/s: 256 CUs x 4 SIMDs, a wave64 instruction per 4 cycles, 2.4 GHz
 
 
 def parse():
@@ -484,6 +485,19 @@ def cornell_config(args, torch, rt, S, device):
             achieved = bpp * nhit * nl / (k_ms * 1e-3) / 1e9
         else:
             nodes_pp = tests_pp = bpp = achieved = None
+        # what does bound it: vector ALU issue.  Instructions per pair from the committed counter pass
+        # (profiles/traffic.json), issue peak = 256 CUs x 4 SIMDs x one wave instruction per 4 cycles at 2.4 GHz
+        valu_roof = None
+        try:
+            ent = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("cornell_shadow")
+            if ent:
+                ginst = ent["valu_insts_per_pair"] * nhit * nl / (k_ms * 1e-3) / 1e9
+                valu_roof = {"achieved": round(ginst, 1), "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
+                             "frac": round(ginst / VALU_PEAK_GINST, 4), "insts_per_pair": round(ent["valu_insts_per_pair"], 2),
+                             "source": ent.get("source"), "commit": ent.get("commit"),
+                             "note": "instruction count from a committed rocprofv3 --pmc pass, not measured by this run"}
+        except Exception:
+            pass
         roof = {"bound": "hbm", "achieved": None if achieved is None else round(achieved, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                 "kernel": kernel_name(layout, False, "shadow-pair generator"), "kernel_ms": round(k_ms, 4),
@@ -491,6 +505,7 @@ def cornell_config(args, torch, rt, S, device):
                 "mean_nodes_visited": nodes_pp, "mean_triangle_tests": tests_pp,
                 "counters_source": "oracle counters on the sampled pairs of this run",
                 "cache_resident": True,
+                "valu": valu_roof,
                 "hbm_bytes_per_pair": round(0.125 + 48.0 / nl, 4),
                 "l2": None if achieved is None else {"achieved": round(achieved, 1), "peak": L2_PEAK_GBS, "unit": "GB/s",
                                                      "frac": round(achieved / L2_PEAK_GBS, 4),
