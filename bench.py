@@ -110,6 +110,22 @@ def traffic_from_profiles(key, layout, n_rays=1 << 24):
     return b, src
 
 
+def valu_roofline(key, units, k_ms):
+    """Vector-ALU issue roofline of a kernel that is bound by it: wave instructions per unit from a committed
+    counter pass (profiles/traffic.json) x the units of this run / the kernel time of this run."""
+    try:
+        ent = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(key)
+        if not ent:
+            return None
+        ginst = ent["valu_insts_per_pair"] * units / (k_ms * 1e-3) / 1e9
+        return {"achieved": round(ginst, 1), "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
+                "frac": round(ginst / VALU_PEAK_GINST, 4), "insts_per_unit": round(ent["valu_insts_per_pair"], 2),
+                "source": ent.get("source"), "commit": ent.get("commit"),
+                "note": "instruction count from a committed rocprofv3 --pmc pass, not measured by this run"}
+    except Exception:
+        return None
+
+
 def kernel_name(layout, closest=True, gen="explicit rays"):
     return "trace_kernel<%s, %s, %s>" % ("triples" if layout == 2 else "pairs", "closest" if closest else "any", gen)
 
@@ -487,17 +503,7 @@ def cornell_config(args, torch, rt, S, device):
             nodes_pp = tests_pp = bpp = achieved = None
         # what does bound it: vector ALU issue.  Instructions per pair from the committed counter pass
         # (profiles/traffic.json), issue peak = 256 CUs x 4 SIMDs x one wave instruction per 4 cycles at 2.4 GHz
-        valu_roof = None
-        try:
-            ent = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("cornell_shadow")
-            if ent:
-                ginst = ent["valu_insts_per_pair"] * nhit * nl / (k_ms * 1e-3) / 1e9
-                valu_roof = {"achieved": round(ginst, 1), "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
-                             "frac": round(ginst / VALU_PEAK_GINST, 4), "insts_per_pair": round(ent["valu_insts_per_pair"], 2),
-                             "source": ent.get("source"), "commit": ent.get("commit"),
-                             "note": "instruction count from a committed rocprofv3 --pmc pass, not measured by this run"}
-        except Exception:
-            pass
+        valu_roof = valu_roofline("cornell_shadow", nhit * nl, k_ms)
         roof = {"bound": "hbm", "achieved": None if achieved is None else round(achieved, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                 "kernel": kernel_name(layout, False, "shadow-pair generator"), "kernel_ms": round(k_ms, 4),
@@ -529,6 +535,7 @@ def cornell_config(args, torch, rt, S, device):
                 "kernel": "transm_shadow_kernel", "kernel_ms": round(k_ms, 4),
                 "algorithmic_bytes_per_segment": round(bpp, 3),
                 "samples_per_s_G": round(9.0 * nhit * nl / (k_ms * 1e-3) / 1e9, 2),
+                "valu": valu_roofline("transmittance", nhit * nl, k_ms),
                 "l2": {"achieved": round(l2, 1), "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": round(l2 / L2_PEAK_GBS, 4),
                        "bytes_per_segment": 72, "what": "9 trilinear samples x one 8-byte corner brick (2.2 MB table, L2-resident)"},
                 "note": "vector-ALU bound: ~100 instructions per trilinear sample (three IEEE divides of the "
