@@ -364,6 +364,7 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": traffic, "traffic_source": traffic_src,
+                         "valu": valu_roofline("bounce" if tess == 158 else "bounce_s%d" % tess, n, k_eff_ms),
                          "kernel": kernel_name(layout), "kernel_ms": round(k_eff_ms, 4),
                          "pipelined": tracer.pipeline,
                          "kernel_ms_events": round(k_ms, 4),
