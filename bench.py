@@ -307,7 +307,7 @@ def main():
             cpum = nm / (time.perf_counter() - t1) / 1e6
             # parity (not timed): the batch against the oracle, in slices; the timed sample is its first slice.
             # At N > 1 only rank 0's shard is checked here (the gather check above covers the other ranks).
-            full_n = n if (args.full_parity and world == 1 and n <= (1 << 24)) else nm
+            full_n = n if (args.full_parity and world == 1 and n <= (1 << 27)) else nm
             id_mis, rel_max, checked = 0, {"t": 0.0, "u": 0.0, "v": 0.0}, 0
             for slo in range(0, full_n, nm):
                 shi = min(full_n, slo + nm)
