@@ -3,6 +3,7 @@ error behaviour without a device, asset I/O and the synthetic input generators."
 import ctypes as C
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -203,3 +204,26 @@ def test_byte_unorm_is_exact_division():
         e = _round_f32(Fraction(-255) * r + fb)        # fmaf(-255, r, b)
         q = _round_f32(e * rcp + r)                     # fmaf(e, rcp, r)
         assert float(q) == float(np.float32(b) / np.float32(255.0)), b
+
+
+def test_committed_counter_passes_feed_the_bench_lines():
+    """bench.py cannot collect hardware counters itself: roofline.traffic and roofline.valu come from
+    profiles/traffic.json, which names the committed rocprofv3 pass each figure was taken from."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    for key in ("bounce", "bounce_s500"):
+        e = t[key]
+        assert e["layout"] == 2 and e["hbm_bytes_per_launch"] > 0 and 5 < e["tcc_miss_per_ray"] < 60
+        assert os.path.exists(os.path.join(ROOT, e["source"])), e["source"]
+        got, src = bench.traffic_from_profiles(key, 2, 1 << 24)
+        assert got == e["hbm_bytes_per_launch"] and src["from"] == e["source"]
+        scaled, src2 = bench.traffic_from_profiles(key, 2, 1 << 27)
+        assert abs(scaled - 8 * got) < 1e-3 * got and "scaled" in src2["note"]
+        assert bench.traffic_from_profiles(key, 1, 1 << 24) == (None, None)     # another layout: no figure
+    for key in ("bounce", "bounce_s500", "cornell_shadow", "transmittance"):
+        v = bench.valu_roofline(key, 1 << 24, 5.0)
+        assert v and 0 < v["frac"] and v["peak"] == bench.VALU_PEAK_GINST
+        assert os.path.exists(os.path.join(ROOT, v["source"].split()[0])), v["source"]
+    assert bench.valu_roofline("no such entry", 1, 1.0) is None
