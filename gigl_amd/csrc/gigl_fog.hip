@@ -158,7 +158,7 @@ int gigl_compute_pi_density_device(const gigl_scene* s, const gigl_fog* f, const
     DeviceGuard g(s->device);
     hipStream_t st = (hipStream_t)stream;
     void* hits = nullptr;
-    HIP_TRY(hipMallocAsync(&hits, n * sizeof(gigl_hit), st));
+    HIP_TRY(gd::pool_alloc(s->device, &hits, n * sizeof(gigl_hit), st));
     int rc = gigl_trace_primary_device(s, cam, res_x, 0, n, (gigl_hit*)hits, stream);
     if (rc == GIGL_OK) {
         Cam12 c;

@@ -329,6 +329,9 @@ int scene_clone_to_device(const gigl_scene* src, int device, gigl_scene** out);
 int trace_closest_ranges(const gigl_scene* s, const float4* o_tmin, const float4* d_tmax, unsigned n, uint4* hits,
                          float2* ranges, float4* hit_tri, hipStream_t st);
 
+// gigl_rt.hip: stream-ordered allocation from the library's own pool on `device` (release with hipFreeAsync)
+hipError_t pool_alloc(int device, void** p, size_t bytes, hipStream_t st);
+
 struct DeviceGuard {
     int prev = -1;
     bool ok = false;

@@ -878,6 +878,51 @@ int scratch_for_device(int device, void** out) {
     return GIGL_OK;
 }
 
+}  // namespace
+namespace gd {
+// Stream-ordered allocations (launch workspaces, staging of the host-pointer calls) come from a pool of the
+// library's own, one per device, not from the device's default pool: with the default reuse policy the
+// runtime hands a block whose hipFreeAsync is still pending on stream A to an allocation on stream B as
+// soon as B has waited on any event of A, also one recorded BEFORE the launch that still uses the block
+// (hipMemPoolReuseFollowEventDependencies; seen on ROCm 7.2 as two concurrent traversals sharing one work
+// counter, tests/test_gpu_streams.py).  This pool reuses a block only on the stream that freed it, or
+// once that free has completed.
+std::mutex g_pool_mu;
+hipMemPool_t g_pool[kMaxDevices] = {nullptr};
+
+hipError_t pool_alloc(int device, void** p, size_t bytes, hipStream_t st) {
+    *p = nullptr;
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    hipMemPool_t pool;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        if (!g_pool[device]) {
+            hipMemPoolProps props = {};
+            props.allocType = hipMemAllocationTypePinned;
+            props.handleTypes = hipMemHandleTypeNone;
+            props.location.type = hipMemLocationTypeDevice;
+            props.location.id = device;
+            hipMemPool_t np = nullptr;
+            hipError_t e = hipMemPoolCreate(&np, &props);
+            if (e != hipSuccess) return e;
+            uint64_t keep = UINT64_MAX;   // the pool keeps its memory between calls
+            int off = 0;
+            e = hipMemPoolSetAttribute(np, hipMemPoolAttrReleaseThreshold, &keep);
+            if (e == hipSuccess) e = hipMemPoolSetAttribute(np, hipMemPoolReuseFollowEventDependencies, &off);
+            if (e == hipSuccess) e = hipMemPoolSetAttribute(np, hipMemPoolReuseAllowInternalDependencies, &off);
+            if (e != hipSuccess) {
+                (void)hipMemPoolDestroy(np);
+                return e;
+            }
+            g_pool[device] = np;
+        }
+        pool = g_pool[device];
+    }
+    return hipMallocFromPoolAsync(p, bytes, pool, st);
+}
+}  // namespace gd
+namespace {
+
 // Workspace handed in by the caller of launch_trace instead of a stream-ordered allocation.
 struct ExtWorkspace {
     void* base;           // 256 bytes of counters, then the spill area
@@ -921,7 +966,7 @@ int launch_trace_t(const gigl_scene* s, TraceParams& P, const Options& opt, hipS
         ws = ext->base;
     } else {
         const size_t spill_entries = spill ? (size_t)grid * BLOCK * (size_t)(32 - STACK_N) : 0;
-        HIP_TRY(hipMallocAsync(&ws, 256 + spill_entries * sizeof(uint4), st));
+        HIP_TRY(gd::pool_alloc(s->device, &ws, 256 + spill_entries * sizeof(uint4), st));
     }
     if (!P.reset_counter && hipMemsetAsync(ws, 0, 256, st) != hipSuccess) {
         if (!ext) (void)hipFreeAsync(ws, st);
@@ -983,7 +1028,7 @@ int launch_trace(const gigl_scene* s, TraceParams& P, hipStream_t st, const ExtW
         const size_t off_hist = 2 * off_perm;
         const size_t off_sums = off_hist + (size_t)n_bins * 4;
         const size_t total = off_sums + (size_t)n_blocks * 4 + 256;
-        if (hipMallocAsync(&sort_ws, total, st) != hipSuccess) return fail(GIGL_ERR_HIP, "hipMallocAsync(regroup)");
+        if (gd::pool_alloc(s->device, &sort_ws, total, st) != hipSuccess) return fail(GIGL_ERR_HIP, "pool_alloc(regroup)");
         unsigned* keys = (unsigned*)sort_ws;
         unsigned* perm = (unsigned*)((char*)sort_ws + off_perm);
         unsigned* hist = (unsigned*)((char*)sort_ws + off_hist);
@@ -1044,11 +1089,6 @@ int scene_device_resources(gigl_scene* s) {
     HIP_TRY(hipMalloc(&s->one_ws, one_ws_bytes));
     HIP_TRY(hipMemset(s->one_ws, 0, 256));
     HIP_TRY(hipStreamCreateWithFlags(&s->one_stream, hipStreamNonBlocking));
-    hipMemPool_t pool;   // keep the stream-ordered pool's memory between calls
-    if (hipDeviceGetDefaultMemPool(&pool, s->device) == hipSuccess) {
-        uint64_t thr = UINT64_MAX;
-        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr);
-    }
     return scratch_for_device(s->device, &s->scratch);
 }
 
@@ -1445,47 +1485,109 @@ int gigl_trace_any_device(const gigl_scene* s, const void* o_tmin, const void* d
     return launch_trace<true, 0>(s, P, (hipStream_t)stream);
 }
 
-static int trace_host(const gigl_scene* s, const float* o_tmin, const float* d_tmax, uint64_t n, void* out,
-                      size_t out_bytes, bool any) {
+// Host-pointer batches.  A batch of more than one chunk is pipelined over three buffer slots: chunk k's
+// rays go up on one stream (in order, so the first chunk has the whole link) while chunk k-1 is traversed
+// (two alternating streams) and chunk k-2's records come down on a third, so that with page-locked host
+// memory the call runs at the rate of the slower link direction (32 B per ray up) instead of the sum of
+// both copies and the traversal.  Pageable memory is staged by the runtime inside hipMemcpyAsync, which
+// then blocks the caller: copies serialise, and only the traversal overlaps (chunk k-1's records are
+// fetched after chunk k's launch for that reason).  Chunks are multiples of 64 rays, so any-hit chunks
+// own whole 64-bit words of the output.  Buffers come from the stream-ordered pool, which keeps them
+// between calls.
+#ifndef GIGL_HOST_PIPELINE
+#define GIGL_HOST_PIPELINE 1
+#endif
+static constexpr uint64_t kHostChunk = 1ull << 21;
+static constexpr int kHostSlots = 3;
+
+namespace {
+struct HostPipe {
+    hipStream_t s_in = nullptr, s_out = nullptr, s_cmp[2] = {nullptr, nullptr};
+    hipEvent_t ev_in[kHostSlots] = {}, ev_k[kHostSlots] = {}, ev_out[kHostSlots] = {};
+    void* d_o[kHostSlots] = {};
+    void* d_d[kHostSlots] = {};
+    void* d_out[kHostSlots] = {};
+    ~HostPipe() {
+        for (hipStream_t st : {s_out, s_cmp[0], s_cmp[1], s_in})
+            if (st) (void)hipStreamSynchronize(st);
+        for (int k = 0; k < kHostSlots; ++k) {
+            if (d_o[k]) (void)hipFreeAsync(d_o[k], s_in);
+            if (d_d[k]) (void)hipFreeAsync(d_d[k], s_in);
+            if (d_out[k]) (void)hipFreeAsync(d_out[k], s_in);
+            for (hipEvent_t e : {ev_in[k], ev_k[k], ev_out[k]})
+                if (e) (void)hipEventDestroy(e);
+        }
+        if (s_in) (void)hipStreamSynchronize(s_in);
+        for (hipStream_t st : {s_out, s_cmp[0], s_cmp[1], s_in})
+            if (st) (void)hipStreamDestroy(st);
+    }
+};
+}  // namespace
+
+static int trace_host(const gigl_scene* s, const float* o_tmin, const float* d_tmax, uint64_t n, void* out, bool any) {
     int rc = check_batch(s, o_tmin, d_tmax, n, out);
     if (rc != GIGL_OK || n == 0) return rc;
     DeviceGuard g(s->device);
-    void *d_o = nullptr, *d_d = nullptr, *d_out = nullptr;
-    auto release = [&]() {
-        if (d_o) (void)hipFree(d_o);
-        if (d_d) (void)hipFree(d_d);
-        if (d_out) (void)hipFree(d_out);
-    };
+    const bool piped = GIGL_HOST_PIPELINE && n > kHostChunk;
+    const uint64_t chunk = piped ? kHostChunk : n;
+    const uint64_t n_chunks = (n + chunk - 1) / chunk;
+    const int S = (int)std::min<uint64_t>(kHostSlots, n_chunks);
+    auto out_bytes = [&](uint64_t m) { return any ? (size_t)((m + 63) / 64 * 8) : (size_t)m * sizeof(gigl_hit); };
+    HostPipe hp;
 #define HOST_TRY(expr)                                                                    \
     do {                                                                                  \
         hipError_t e_ = (expr);                                                           \
-        if (e_ != hipSuccess) {                                                           \
-            release();                                                                    \
-            return fail(GIGL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
-        }                                                                                 \
+        if (e_ != hipSuccess) return fail(GIGL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
-    HOST_TRY(hipMalloc(&d_o, n * 16));
-    HOST_TRY(hipMalloc(&d_d, n * 16));
-    HOST_TRY(hipMalloc(&d_out, out_bytes));
-    HOST_TRY(hipMemcpy(d_o, o_tmin, n * 16, hipMemcpyHostToDevice));
-    HOST_TRY(hipMemcpy(d_d, d_tmax, n * 16, hipMemcpyHostToDevice));
-    rc = any ? gigl_trace_any_device(s, d_o, d_d, n, (uint64_t*)d_out, nullptr)
-             : gigl_trace_closest_device(s, d_o, d_d, n, (gigl_hit*)d_out, nullptr);
-    if (rc != GIGL_OK) { release(); return rc; }
-    HOST_TRY(hipDeviceSynchronize());
-    HOST_TRY(hipMemcpy(out, d_out, out_bytes, hipMemcpyDeviceToHost));
+    HOST_TRY(hipStreamCreateWithFlags(&hp.s_in, hipStreamNonBlocking));
+    HOST_TRY(hipStreamCreateWithFlags(&hp.s_out, hipStreamNonBlocking));
+    for (int k = 0; k < (piped ? 2 : 1); ++k) HOST_TRY(hipStreamCreateWithFlags(&hp.s_cmp[k], hipStreamNonBlocking));
+    for (int k = 0; k < S; ++k) {
+        HOST_TRY(hipEventCreateWithFlags(&hp.ev_in[k], hipEventDisableTiming));
+        HOST_TRY(hipEventCreateWithFlags(&hp.ev_k[k], hipEventDisableTiming));
+        HOST_TRY(hipEventCreateWithFlags(&hp.ev_out[k], hipEventDisableTiming));
+        HOST_TRY(gd::pool_alloc(s->device, &hp.d_o[k], chunk * 16, hp.s_in));
+        HOST_TRY(gd::pool_alloc(s->device, &hp.d_d[k], chunk * 16, hp.s_in));
+        HOST_TRY(gd::pool_alloc(s->device, &hp.d_out[k], out_bytes(chunk), hp.s_in));
+    }
+    // iteration k: rays of chunk k up, chunk k launched, records of chunk k-1 down
+    for (uint64_t k = 0; k <= n_chunks; ++k) {
+        if (k < n_chunks) {
+            const int slot = (int)(k % (uint64_t)S);
+            const uint64_t lo = k * chunk, m = std::min(chunk, n - lo);
+            if (k >= (uint64_t)S) HOST_TRY(hipStreamWaitEvent(hp.s_in, hp.ev_k[slot], 0));   // chunk k-S has been traversed
+            HOST_TRY(hipMemcpyAsync(hp.d_o[slot], o_tmin + lo * 4, m * 16, hipMemcpyHostToDevice, hp.s_in));
+            HOST_TRY(hipMemcpyAsync(hp.d_d[slot], d_tmax + lo * 4, m * 16, hipMemcpyHostToDevice, hp.s_in));
+            HOST_TRY(hipEventRecord(hp.ev_in[slot], hp.s_in));
+            hipStream_t c = hp.s_cmp[piped ? (k & 1) : 0];
+            HOST_TRY(hipStreamWaitEvent(c, hp.ev_in[slot], 0));
+            if (k >= (uint64_t)S) HOST_TRY(hipStreamWaitEvent(c, hp.ev_out[slot], 0));       // chunk k-S's records have left
+            rc = any ? gigl_trace_any_device(s, hp.d_o[slot], hp.d_d[slot], m, (uint64_t*)hp.d_out[slot], c)
+                     : gigl_trace_closest_device(s, hp.d_o[slot], hp.d_d[slot], m, (gigl_hit*)hp.d_out[slot], c);
+            if (rc != GIGL_OK) return rc;
+            HOST_TRY(hipEventRecord(hp.ev_k[slot], c));
+        }
+        if (k >= 1) {
+            const int slot = (int)((k - 1) % (uint64_t)S);
+            const uint64_t lo = (k - 1) * chunk, m = std::min(chunk, n - lo);
+            char* dst = (char*)out + (any ? (size_t)(lo / 64 * 8) : (size_t)lo * sizeof(gigl_hit));
+            HOST_TRY(hipStreamWaitEvent(hp.s_out, hp.ev_k[slot], 0));
+            HOST_TRY(hipMemcpyAsync(dst, hp.d_out[slot], out_bytes(m), hipMemcpyDeviceToHost, hp.s_out));
+            HOST_TRY(hipEventRecord(hp.ev_out[slot], hp.s_out));
+        }
+    }
+    HOST_TRY(hipStreamSynchronize(hp.s_out));
 #undef HOST_TRY
-    release();
-    return GIGL_OK;
+    return GIGL_OK;   // ~HostPipe drains the other streams and returns the buffers to the pool
 }
 
 int gigl_trace_closest(const gigl_scene* s, const float* o_tmin, const float* d_tmax, uint64_t n, gigl_hit* hits) {
-    return trace_host(s, o_tmin, d_tmax, n, hits, n * sizeof(gigl_hit), false);
+    return trace_host(s, o_tmin, d_tmax, n, hits, false);
 }
 
 int gigl_trace_any(const gigl_scene* s, const float* o_tmin, const float* d_tmax, uint64_t n,
                    uint64_t* occluded_bits) {
-    return trace_host(s, o_tmin, d_tmax, n, occluded_bits, (n + 63) / 64 * 8, true);
+    return trace_host(s, o_tmin, d_tmax, n, occluded_bits, true);
 }
 
 int gigl_trace_closest_noalloc_device(const gigl_scene* s, const void* o_tmin, const void* d_tmax, uint64_t n,
@@ -1673,7 +1775,7 @@ static int shadow_batch(const gigl_scene* s, const void* prim_o_tmin, const void
     // the per-point half of the pairs, computed once per point (worth it from a few lights per point on)
     void* cache = nullptr;
     if (n_lights >= 4u) {
-        HIP_TRY(hipMallocAsync(&cache, (size_t)n_pts * 2 * sizeof(float4), (hipStream_t)stream));
+        HIP_TRY(gd::pool_alloc(s->device, &cache, (size_t)n_pts * 2 * sizeof(float4), (hipStream_t)stream));
         hipLaunchKernelGGL(shadow_points_kernel, dim3(stream_grid(s, n_pts)), dim3(256), 0, (hipStream_t)stream, P,
                            (unsigned)n_pts, (float4*)cache);
         P.pt_cache = (const float4*)cache;

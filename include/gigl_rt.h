@@ -98,7 +98,10 @@ int gigl_scene_layout(const gigl_scene* s, int* layout_out);
 int gigl_scene_export_tree(const gigl_scene* s, uint32_t* nodes_words, uint32_t* leaf_prim_ids);
 
 /* Scene::trace(ray, false) over a batch (Source/Common/Scene.cpp:234-243 ->
- * KdTree::intersect, Source/RT/KdTree.hpp:266-347).  n < 2^32. */
+ * KdTree::intersect, Source/RT/KdTree.hpp:266-347).  n < 2^32.  The variants without _device take
+ * host pointers and return when the records are in host memory; batches of more than 2^21 rays are
+ * pipelined (rays up, traversal and records down overlap on streams of the call's own), at the
+ * link's rate when the arrays are page-locked. */
 int gigl_trace_closest_device(const gigl_scene* s, const void* o_tmin, const void* d_tmax, uint64_t n,
                               gigl_hit* hits, void* stream);
 int gigl_trace_closest(const gigl_scene* s, const float* o_tmin, const float* d_tmax, uint64_t n,

@@ -1,0 +1,95 @@
+"""Launches that overlap on one GPU: several streams tied together by events, and the host-pointer calls,
+which pipeline a large batch over copy and traversal streams of their own (gigl_rt.hip, trace_host).
+
+Both once produced wrong records: the device's default stream-ordered pool gave a launch on stream B the
+workspace whose hipFreeAsync was still pending on stream A (B had waited on an earlier event of A), so two
+traversals in flight shared one work counter.  The engine allocates from a pool of its own since.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from gigl_amd import rt, scene_io as S, synth
+from oracle import oracle_py as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def s64(cornell):
+    import torch
+    V, T = synth.tessellate(cornell["verts"], cornell["tris"], 64)
+    g = rt.Scene(V, T, device=0, **S.KD_PARAMS)
+    n = 3 * (1 << 21) + 12345             # four chunks of the host-pointer pipeline, the last one ragged
+    ro, rd = synth.bounce_rays(V, T, n, 0x5EED57, n_threads=8)
+    d_o, d_d = torch.from_numpy(ro).cuda(), torch.from_numpy(rd).cuda()
+    ref = torch.empty((n, 4), dtype=torch.int32, device="cuda")
+    g.trace_closest_device(d_o.data_ptr(), d_d.data_ptr(), n, ref.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    want = ref.cpu().numpy()
+    # the single-stream records themselves against the oracle (on the engine's exported tree), first 2^15 rays
+    ora = O.OracleScene(V, T, tree=g.export_tree())
+    m = 1 << 15
+    w = ora.trace_closest(ro[:m], rd[:m], n_threads=4)
+    got = want[:m].view(rt.HIT_DTYPE).reshape(-1)
+    assert np.array_equal(got["tri_id"], w["tri_id"])
+    hit = got["tri_id"] != rt.GIGL_MISS
+    for k in ("t", "u", "v"):
+        assert np.array_equal(got[k][hit].view(np.uint32), w[k][hit].view(np.uint32)), k
+    yield {"gpu": g, "n": n, "ro": ro, "rd": rd, "d_o": d_o, "d_d": d_d, "want": want}
+    g.close()
+
+
+def test_launches_on_event_linked_streams(s64):
+    """B waits on an event A recorded BEFORE A's launch, then both traverse at the same time."""
+    import torch
+    g, n, want = s64["gpu"], s64["n"], torch.from_numpy(s64["want"]).cuda()
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    out_a = torch.empty((n, 4), dtype=torch.int32, device="cuda")
+    out_b = torch.empty((n, 4), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    for it in range(12):
+        out_a.zero_(); out_b.zero_()
+        torch.cuda.synchronize()
+        ev = torch.cuda.Event()
+        ev.record(a)
+        g.trace_closest_device(s64["d_o"].data_ptr(), s64["d_d"].data_ptr(), n, out_a.data_ptr(), a.cuda_stream)
+        b.wait_event(ev)
+        g.trace_closest_device(s64["d_o"].data_ptr(), s64["d_d"].data_ptr(), n, out_b.data_ptr(), b.cuda_stream)
+        ev2 = torch.cuda.Event()
+        ev2.record(b)
+        a.wait_event(ev2)                  # and the other way round for the next round
+        torch.cuda.synchronize()
+        assert bool((out_a == want).all()) and bool((out_b == want).all()), "round %d" % it
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+def test_host_pointer_batches_are_pipelined_correctly(s64, pinned):
+    """gigl_trace_closest / gigl_trace_any on more rays than one chunk, pageable and page-locked buffers."""
+    import torch
+    g, n, want = s64["gpu"], s64["n"], s64["want"]
+    L = rt.lib()
+    keep = []
+    if pinned:
+        t_o, t_d = torch.from_numpy(s64["ro"]).pin_memory(), torch.from_numpy(s64["rd"]).pin_memory()
+        t_h = torch.zeros((n, 4), dtype=torch.int32).pin_memory()
+        t_b = torch.zeros((n + 63) // 64, dtype=torch.int64).pin_memory()
+        keep = [t_o, t_d, t_h, t_b]
+        o_ptr, d_ptr, h_ptr, b_ptr = t_o.data_ptr(), t_d.data_ptr(), t_h.data_ptr(), t_b.data_ptr()
+        hits, bits = t_h.numpy(), t_b.numpy().view(np.uint64)
+    else:
+        hits, bits = np.zeros((n, 4), np.int32), np.zeros((n + 63) // 64, np.uint64)
+        o_ptr, d_ptr, h_ptr, b_ptr = s64["ro"].ctypes.data, s64["rd"].ctypes.data, hits.ctypes.data, bits.ctypes.data
+    for it in range(4):
+        hits[:] = 0
+        bits[:] = 0
+        assert L.gigl_trace_closest(g.h, C.c_void_p(o_ptr), C.c_void_p(d_ptr), n, C.c_void_p(h_ptr)) == 0, L.gigl_last_error()
+        assert np.array_equal(hits, want), "closest, call %d: %d records differ" % (it, int((hits != want).any(1).sum()))
+        assert L.gigl_trace_any(g.h, C.c_void_p(o_ptr), C.c_void_p(d_ptr), n, C.c_void_p(b_ptr)) == 0, L.gigl_last_error()
+        assert np.array_equal(rt.unpack_bits(bits, n), (want[:, 0] != -1).astype(np.uint8)), "any, call %d" % it
+    # a batch of exactly one chunk and one just above it
+    for m in (1 << 21, (1 << 21) + 1):
+        assert L.gigl_trace_closest(g.h, C.c_void_p(o_ptr), C.c_void_p(d_ptr), m, C.c_void_p(h_ptr)) == 0
+        assert np.array_equal(hits[:m], want[:m])
+    del keep
