@@ -1487,13 +1487,13 @@ int gigl_trace_any_device(const gigl_scene* s, const void* o_tmin, const void* d
 
 // Host-pointer batches.  A batch of more than one chunk is pipelined over three buffer slots: chunk k's
 // rays go up on one stream (in order, so the first chunk has the whole link) while chunk k-1 is traversed
-// (two alternating streams) and chunk k-2's records come down on a third, so that with page-locked host
-// memory the call runs at the rate of the slower link direction (32 B per ray up) instead of the sum of
-// both copies and the traversal.  Pageable memory is staged by the runtime inside hipMemcpyAsync, which
-// then blocks the caller: copies serialise, and only the traversal overlaps (chunk k-1's records are
-// fetched after chunk k's launch for that reason).  Chunks are multiples of 64 rays, so any-hit chunks
-// own whole 64-bit words of the output.  Buffers come from the stream-ordered pool, which keeps them
-// between calls.
+// and its records come down on one of two alternating streams, so that with page-locked host memory the
+// call runs near the rate of the slower link direction (32 B per ray up) instead of the sum of both copies
+// and the traversal.  (Records on a stream of their own measured 13 % slower: the runtime maps streams
+// onto few hardware queues.)  Pageable memory is staged by the runtime inside hipMemcpyAsync, which then
+// blocks the caller: copies serialise, and only the traversal overlaps (chunk k-1's records are fetched
+// after chunk k's launch for that reason).  Chunks are multiples of 64 rays, so any-hit chunks own whole
+// 64-bit words of the output.  Buffers come from the library's pool, which keeps them between calls.
 #ifndef GIGL_HOST_PIPELINE
 #define GIGL_HOST_PIPELINE 1
 #endif
@@ -1502,13 +1502,13 @@ static constexpr int kHostSlots = 3;
 
 namespace {
 struct HostPipe {
-    hipStream_t s_in = nullptr, s_out = nullptr, s_cmp[2] = {nullptr, nullptr};
+    hipStream_t s_in = nullptr, s_cmp[2] = {nullptr, nullptr};
     hipEvent_t ev_in[kHostSlots] = {}, ev_k[kHostSlots] = {}, ev_out[kHostSlots] = {};
     void* d_o[kHostSlots] = {};
     void* d_d[kHostSlots] = {};
     void* d_out[kHostSlots] = {};
     ~HostPipe() {
-        for (hipStream_t st : {s_out, s_cmp[0], s_cmp[1], s_in})
+        for (hipStream_t st : {s_cmp[0], s_cmp[1], s_in})
             if (st) (void)hipStreamSynchronize(st);
         for (int k = 0; k < kHostSlots; ++k) {
             if (d_o[k]) (void)hipFreeAsync(d_o[k], s_in);
@@ -1518,7 +1518,7 @@ struct HostPipe {
                 if (e) (void)hipEventDestroy(e);
         }
         if (s_in) (void)hipStreamSynchronize(s_in);
-        for (hipStream_t st : {s_out, s_cmp[0], s_cmp[1], s_in})
+        for (hipStream_t st : {s_cmp[0], s_cmp[1], s_in})
             if (st) (void)hipStreamDestroy(st);
     }
 };
@@ -1540,7 +1540,6 @@ static int trace_host(const gigl_scene* s, const float* o_tmin, const float* d_t
         if (e_ != hipSuccess) return fail(GIGL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
     HOST_TRY(hipStreamCreateWithFlags(&hp.s_in, hipStreamNonBlocking));
-    HOST_TRY(hipStreamCreateWithFlags(&hp.s_out, hipStreamNonBlocking));
     for (int k = 0; k < (piped ? 2 : 1); ++k) HOST_TRY(hipStreamCreateWithFlags(&hp.s_cmp[k], hipStreamNonBlocking));
     for (int k = 0; k < S; ++k) {
         HOST_TRY(hipEventCreateWithFlags(&hp.ev_in[k], hipEventDisableTiming));
@@ -1571,12 +1570,13 @@ static int trace_host(const gigl_scene* s, const float* o_tmin, const float* d_t
             const int slot = (int)((k - 1) % (uint64_t)S);
             const uint64_t lo = (k - 1) * chunk, m = std::min(chunk, n - lo);
             char* dst = (char*)out + (any ? (size_t)(lo / 64 * 8) : (size_t)lo * sizeof(gigl_hit));
-            HOST_TRY(hipStreamWaitEvent(hp.s_out, hp.ev_k[slot], 0));
-            HOST_TRY(hipMemcpyAsync(dst, hp.d_out[slot], out_bytes(m), hipMemcpyDeviceToHost, hp.s_out));
-            HOST_TRY(hipEventRecord(hp.ev_out[slot], hp.s_out));
+            hipStream_t c = hp.s_cmp[piped ? ((k - 1) & 1) : 0];   // behind the chunk's traversal, in stream order
+            HOST_TRY(hipMemcpyAsync(dst, hp.d_out[slot], out_bytes(m), hipMemcpyDeviceToHost, c));
+            HOST_TRY(hipEventRecord(hp.ev_out[slot], c));
         }
     }
-    HOST_TRY(hipStreamSynchronize(hp.s_out));
+    for (hipStream_t c : {hp.s_cmp[0], hp.s_cmp[1]})
+        if (c) HOST_TRY(hipStreamSynchronize(c));
 #undef HOST_TRY
     return GIGL_OK;   // ~HostPipe drains the other streams and returns the buffers to the pool
 }
