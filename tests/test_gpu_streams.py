@@ -93,3 +93,31 @@ def test_host_pointer_batches_are_pipelined_correctly(s64, pinned):
         assert L.gigl_trace_closest(g.h, C.c_void_p(o_ptr), C.c_void_p(d_ptr), m, C.c_void_p(h_ptr)) == 0
         assert np.array_equal(hits[:m], want[:m])
     del keep
+
+
+def test_host_pointer_batches_from_two_host_threads(s64):
+    """Two host threads inside pipelined host-pointer calls on one scene at the same time (ctypes drops the
+    GIL): each call has streams and buffer slots of its own, the pool and the scene are shared."""
+    import threading
+    g, n, want = s64["gpu"], s64["n"], s64["want"].view(rt.HIT_DTYPE).reshape(-1)
+    half = (n // 2) & ~63
+    parts = [(0, half + 777), (half, n)]          # overlapping ranges, both longer than one chunk
+    out, err = [None, None], []
+
+    def work(k):
+        try:
+            lo, hi = parts[k]
+            for _ in range(3):
+                out[k] = g.trace(s64["ro"][lo:hi], s64["rd"][lo:hi])
+                assert np.array_equal(out[k].view(np.uint32), want[lo:hi].view(np.uint32)), "thread %d" % k
+                occ = g.trace(s64["ro"][lo:hi], s64["rd"][lo:hi], is_vis_ray=True)
+                assert np.array_equal(occ, (want["tri_id"][lo:hi] != rt.GIGL_MISS).astype(np.uint8)), "thread %d any" % k
+        except BaseException as e:   # noqa: BLE001 - reported in the main thread
+            err.append(e)
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not err, err
