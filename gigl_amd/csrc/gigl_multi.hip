@@ -43,12 +43,19 @@ void range_of(uint64_t n, int parts, int k, uint64_t& lo, uint64_t& hi) {
 }
 
 // Runs on the replica's own host thread.  src_dev >= 0: rays and hits are device pointers on
-// src_dev; src_dev < 0: host pointers.
+// src_dev; src_dev < 0: host pointers (handed to the replica's own host-pointer call).
 int run_range(gigl_multi::Replica& R, bool root, const char* o, const char* d, char* hits, uint64_t lo, uint64_t hi,
               int src_dev, std::string& err) {
     const uint64_t m = hi - lo;
     if (m == 0) return GIGL_OK;
     gigl_scene* s = R.scene;
+    if (src_dev < 0) {
+        // host pointers: every device fetches and returns its own range through the pipelined host-pointer
+        // call (gigl_rt.hip, trace_host): uploads, traversal and downloads of a range overlap, and so do the devices
+        const int rc = gigl_trace_closest(s, (const float*)(o + lo * 16), (const float*)(d + lo * 16), m, (gigl_hit*)(hits + lo * 16));
+        if (rc != GIGL_OK) err = gigl_last_error();
+        return rc;
+    }
     DeviceGuard g(s->device);
     auto hip_fail = [&](const char* what, hipError_t e) {
         err = std::string(what) + ": " + hipGetErrorString(e);
@@ -73,21 +80,15 @@ int run_range(gigl_multi::Replica& R, bool root, const char* o, const char* d, c
     void* th = hits + lo * 16;
     hipError_t e = hipSuccess;
     if (!in_place) {
-        if (src_dev >= 0) {
-            e = hipMemcpyPeerAsync(R.d_o, s->device, to, src_dev, m * 16, R.stream);
-            if (e == hipSuccess) e = hipMemcpyPeerAsync(R.d_d, s->device, td, src_dev, m * 16, R.stream);
-        } else {
-            e = hipMemcpyAsync(R.d_o, to, m * 16, hipMemcpyHostToDevice, R.stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(R.d_d, td, m * 16, hipMemcpyHostToDevice, R.stream);
-        }
+        e = hipMemcpyPeerAsync(R.d_o, s->device, to, src_dev, m * 16, R.stream);
+        if (e == hipSuccess) e = hipMemcpyPeerAsync(R.d_d, s->device, td, src_dev, m * 16, R.stream);
         if (e != hipSuccess) return hip_fail("ray scatter", e);
         to = R.d_o; td = R.d_d; th = R.d_hits;
     }
     int rc = gigl_trace_closest_device(s, to, td, m, (gigl_hit*)th, R.stream);
     if (rc != GIGL_OK) { err = gigl_last_error(); return rc; }
     if (!in_place) {
-        if (src_dev >= 0) e = hipMemcpyPeerAsync(hits + lo * 16, src_dev, R.d_hits, s->device, m * 16, R.stream);
-        else e = hipMemcpyAsync(hits + lo * 16, R.d_hits, m * 16, hipMemcpyDeviceToHost, R.stream);
+        e = hipMemcpyPeerAsync(hits + lo * 16, src_dev, R.d_hits, s->device, m * 16, R.stream);
         if (e != hipSuccess) return hip_fail("hit gather", e);
     }
     e = hipStreamSynchronize(R.stream);

@@ -121,3 +121,14 @@ def test_host_pointer_batches_from_two_host_threads(s64):
     for t in th:
         t.join()
     assert not err, err
+
+
+def test_multi_device_host_pointer_ranges_are_pipelined(s64):
+    """gigl_multi_trace_closest (host pointers) over a list that repeats device 0: three replicas, each inside
+    its own pipelined host-pointer call at the same time, every range longer than one chunk."""
+    g, want = s64["gpu"], s64["want"]
+    m = rt.MultiDeviceScene(g, [0, 0, 0])
+    for _ in range(2):
+        got = m.trace(s64["ro"], s64["rd"])
+        assert np.array_equal(got.view(np.uint32).reshape(-1, 4), want.view(np.uint32))
+    m.close()
