@@ -304,6 +304,8 @@ struct gigl_scene {
     // gigl_photon_trace_batch: a workspace kept between calls (grown on demand), used on one_stream under one_mu
     void* photon_ws = nullptr;
     size_t photon_ws_bytes = 0;
+    std::vector<float> photon_mats;      // the materials last uploaded into photon_ws, and where
+    const void* photon_mats_at = nullptr;
 };
 
 struct gigl_fog {
@@ -326,8 +328,11 @@ namespace gd {
 // gigl_rt.hip, used by the multi-device entry points (gigl_multi.hip).
 int scene_clone_to_device(const gigl_scene* src, int device, gigl_scene** out);
 // gigl_rt.hip: closest-hit batch with per-ray final ranges and hit triangle records (gigl_photon.hip)
+// With a workspace of the caller's (trace_workspace_bytes(ws_blocks) bytes, its first word zero at launch) the call
+// neither allocates nor clears anything; the launch is held to ws_blocks workgroups.
 int trace_closest_ranges(const gigl_scene* s, const float4* o_tmin, const float4* d_tmax, unsigned n, uint4* hits,
-                         float2* ranges, float4* hit_tri, hipStream_t st);
+                         float2* ranges, float4* hit_tri, hipStream_t st, void* ws = nullptr, unsigned ws_blocks = 0);
+size_t trace_workspace_bytes(unsigned blocks);
 
 // gigl_rt.hip: stream-ordered allocation from the library's own pool on `device` (release with hipFreeAsync)
 hipError_t pool_alloc(int device, void** p, size_t bytes, hipStream_t st);

@@ -15,6 +15,8 @@
 // cos, sin, log and pow are evaluated in double precision and rounded to float: the correctly rounded
 // float result, the same on host and device, which no float libm guarantees.  Everything else is the
 // float arithmetic of the reference in the reference's order (-ffp-contract=off).
+#include <cstring>
+
 #include "gigl_internal.h"
 
 using namespace gd;
@@ -96,6 +98,9 @@ struct WalkParams {
     float abs_k, sca_k, maj_ext_k;
     float src[3], src_int[3];
     unsigned* error;          // set when a hit triangle names a material beyond n_mat
+    unsigned* trace_counter;  // the traversal launches' work counter: the walk's kernels leave it at zero for the next one
+    unsigned* totals;         // the running totals (Acc, 8 words) and the error word behind them...
+    unsigned n_total_words;   // ...cleared by the first block's start kernel when > 0
 };
 
 __device__ __forceinline__ void store_ray(const WalkParams& W, unsigned i, F3 o, F3 d) {
@@ -112,6 +117,8 @@ __device__ __forceinline__ void retire(const WalkParams& W, unsigned i, PathStat
 // PhotonTracer.cpp:84-93: the start of a path
 __global__ void __launch_bounds__(256) photon_start_kernel(const WalkParams W) {
     const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i == 0u) *W.trace_counter = 0u;
+    if (i < W.n_total_words) W.totals[i] = 0u;
     if (i >= W.n) return;
     Draw draw{path_key(W.seed, W.first + i), 0u};
     if (W.src[2] <= kMaxFogHeight) (void)draw();   // :86 — the draw is made, its result never reaches the path (:88-92)
@@ -134,6 +141,7 @@ __device__ __forceinline__ float sample_density(const FogParams& F, F3 p) {   //
 // PhotonTracer.cpp:95-178: what happens to a path after scene.trace(ray), one lane per path
 __global__ void __launch_bounds__(256) photon_bounce_kernel(const WalkParams W, int last_bounce) {
     const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i == 0u) *W.trace_counter = 0u;
     if (i >= W.n) return;
     PathState st = W.state[i];
     if (!st.alive) return;
@@ -320,6 +328,7 @@ __global__ void __launch_bounds__(256) vpl_scan_sums_kernel(unsigned long long* 
         if (b < n_blocks) sums[b] = run + excl;
         run += total;
     }
+    if (threadIdx.x == 0) sums[n_blocks] = run;   // the grand total, for vpl_advance_kernel
 }
 __global__ void __launch_bounds__(256) vpl_gather_kernel(const PathState* st, const VplRec* slots, unsigned first,
                                                          unsigned n, const unsigned long long* sums, unsigned max_vpl,
@@ -345,19 +354,17 @@ __global__ void __launch_bounds__(256) vpl_gather_kernel(const PathState* st, co
     }
 }
 // after the gather of a block of paths (single thread): totals for the next block
-__global__ void vpl_advance_kernel(const PathState* st, const unsigned long long* sums, unsigned n, Acc* acc,
-                                   const unsigned* error) {
-    const unsigned last_block = (n - 1u) / 256u;
-    unsigned long long tot = sums[last_block];
-    for (unsigned i = last_block * 256u; i < n; ++i) tot += path_counts(st[i]);
+__global__ void vpl_advance_kernel(const unsigned long long* sums, unsigned n_blocks, Acc* acc, const unsigned* error) {
+    const unsigned long long tot = sums[n_blocks];
     acc->size += (unsigned)(tot & 0xFFFFFFFFull);
     acc->contrib += (unsigned)(tot >> 32);
     if (*error) acc->error = 1u;
 }
-__global__ void __launch_bounds__(256) vpl_normalize_kernel(VplRec* out, unsigned n, unsigned n_paths) {
+// launched after every block of paths; acts once, when the block has supplied record number max_vpl_count
+__global__ void __launch_bounds__(256) vpl_normalize_kernel(VplRec* out, unsigned n, const Acc* acc) {
     const unsigned i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
-    const float inv = 1.0f / (float)(int)n_paths;   // LightArray.hpp:47
+    if (i >= n || !acc->done) return;
+    const float inv = 1.0f / (float)(int)acc->n_paths;   // LightArray.hpp:47
     for (int k = 4; k < 7; ++k) out[i].w[k] = __float_as_uint(__uint_as_float(out[i].w[k]) * inv);
 }
 
@@ -392,8 +399,11 @@ extern "C" int gigl_photon_trace_batch(const gigl_scene* s, const gigl_fog* fog,
     const size_t o_hits = take((size_t)P * 16), o_rng = take((size_t)P * 8), o_tri = take((size_t)P * 48);
     const size_t o_slots = take((size_t)P * kGiBounces * sizeof(VplRec));
     const size_t o_out = take((size_t)max_vpl_count * sizeof(VplRec));
-    const size_t o_sums = take((size_t)n_blocks * 8), o_acc = take(sizeof(Acc)), o_err = take(4);
+    const size_t o_sums = take(((size_t)n_blocks + 1) * 8), o_acc = take(sizeof(Acc)), o_err = take(4);
     const size_t o_mat = take((size_t)n_mat * 48);
+    // the traversal launches' workspace (work counter + stack spill area), so that they neither allocate nor clear
+    const unsigned trace_blocks = std::min<unsigned>(n_blocks, (unsigned)s->n_cus * 6u);
+    const size_t o_tws = take(trace_workspace_bytes(trace_blocks));
     // the workspace and the stream belong to the scene and are kept between calls (a 150-VPL set is a
     // dozen short launches: allocating per call would cost as much as the walk); calls on one scene serialise
     gigl_scene* ms = const_cast<gigl_scene*>(s);
@@ -401,6 +411,7 @@ extern "C" int gigl_photon_trace_batch(const gigl_scene* s, const gigl_fog* fog,
     if (ms->photon_ws_bytes < off) {
         if (ms->photon_ws) { (void)hipStreamSynchronize(ms->one_stream); (void)hipFree(ms->photon_ws); }
         ms->photon_ws = nullptr; ms->photon_ws_bytes = 0;
+        ms->photon_mats.clear(); ms->photon_mats_at = nullptr;
         HIP_TRY(hipMalloc(&ms->photon_ws, off));
         ms->photon_ws_bytes = off;
     }
@@ -409,8 +420,14 @@ extern "C" int gigl_photon_trace_batch(const gigl_scene* s, const gigl_fog* fog,
     int rc = GIGL_OK;
     Acc acc = {};
     auto run = [&]() -> int {
-        HIP_TRY(hipMemsetAsync(ws + o_acc, 0, (o_err + 4) - o_acc, st));
-        HIP_TRY(hipMemcpyAsync(ws + o_mat, materials, (size_t)n_mat * 48, hipMemcpyHostToDevice, st));
+        // materials travel only when they differ from the last call's (a renderer passes the same ones every frame)
+        if (ms->photon_mats.size() != (size_t)n_mat * 12 || ms->photon_mats_at != ws + o_mat ||
+            std::memcmp(ms->photon_mats.data(), materials, (size_t)n_mat * 48) != 0) {
+            ms->photon_mats.clear();   // no stale match if the copy fails
+            HIP_TRY(hipMemcpyAsync(ws + o_mat, materials, (size_t)n_mat * 48, hipMemcpyHostToDevice, st));
+            ms->photon_mats.assign(materials, materials + (size_t)n_mat * 12);
+            ms->photon_mats_at = ws + o_mat;
+        }
         WalkParams W = {};
         W.state = (PathState*)(ws + o_state);
         W.o_tmin = (float4*)(ws + o_o); W.d_tmax = (float4*)(ws + o_d);
@@ -426,6 +443,9 @@ extern "C" int gigl_photon_trace_batch(const gigl_scene* s, const gigl_fog* fog,
         W.abs_k = abs_k; W.sca_k = sca_k; W.maj_ext_k = maj_ext_k;
         for (int a = 0; a < 3; ++a) { W.src[a] = ppl_pos[a]; W.src_int[a] = ppl_intens[a]; }
         W.error = (unsigned*)(ws + o_err);
+        W.trace_counter = (unsigned*)(ws + o_tws);
+        W.totals = (unsigned*)(ws + o_acc);
+        static_assert(sizeof(Acc) == 32, "Acc is 8 words; the error word follows at the next 256-byte step");
         unsigned long long* sums = (unsigned long long*)(ws + o_sums);
         Acc* d_acc = (Acc*)(ws + o_acc);
         VplRec* d_out = (VplRec*)(ws + o_out);
@@ -434,10 +454,11 @@ extern "C" int gigl_photon_trace_batch(const gigl_scene* s, const gigl_fog* fog,
             const unsigned nb = (unsigned)std::min<uint64_t>(P, path_limit - first);
             const unsigned grid = (nb + 255u) / 256u;
             W.first = (unsigned)first; W.n = nb;
+            W.n_total_words = first == 0 ? (unsigned)((o_err + 4 - o_acc) / 4) : 0u;
             hipLaunchKernelGGL(photon_start_kernel, dim3(grid), dim3(256), 0, st, W);
             for (int b = 1; b <= kGiBounces; ++b) {
                 int trc = trace_closest_ranges(s, W.o_tmin, W.d_tmax, nb, (uint4*)(ws + o_hits), (float2*)(ws + o_rng),
-                                               (float4*)(ws + o_tri), st);
+                                               (float4*)(ws + o_tri), st, ws + o_tws, trace_blocks);
                 if (trc != GIGL_OK) return trc;
                 hipLaunchKernelGGL(photon_bounce_kernel, dim3(grid), dim3(256), 0, st, W, b == kGiBounces ? 1 : 0);
             }
@@ -445,23 +466,36 @@ extern "C" int gigl_photon_trace_batch(const gigl_scene* s, const gigl_fog* fog,
             hipLaunchKernelGGL(vpl_scan_sums_kernel, dim3(1), dim3(256), 0, st, sums, grid);
             hipLaunchKernelGGL(vpl_gather_kernel, dim3(grid), dim3(256), 0, st, W.state, W.slots, W.first, nb, sums,
                                (unsigned)max_vpl_count, d_acc, d_out);
-            hipLaunchKernelGGL(vpl_advance_kernel, dim3(1), dim3(1), 0, st, W.state, sums, nb, d_acc, W.error);
+            hipLaunchKernelGGL(vpl_advance_kernel, dim3(1), dim3(1), 0, st, sums, grid, d_acc, W.error);
+            hipLaunchKernelGGL(vpl_normalize_kernel, dim3(((unsigned)max_vpl_count + 255u) / 256u), dim3(256), 0, st, d_out,
+                               (unsigned)max_vpl_count, d_acc);
             HIP_TRY(hipGetLastError());
-            HIP_TRY(hipMemcpyAsync(&acc, d_acc, sizeof(Acc), hipMemcpyDeviceToHost, st));
+            // totals into the scene's page-locked staging (gigl_trace_one's, free while one_mu is held): a copy
+            // into pageable memory would block the caller once more
+            static_assert(sizeof(Acc) <= 7 * sizeof(float4), "Acc fits the scene's pinned staging");
+            HIP_TRY(hipMemcpyAsync(ms->h_one, d_acc, sizeof(Acc), hipMemcpyDeviceToHost, st));
+            // the first block of paths nearly always supplies the whole set: its records come back behind the
+            // totals, one synchronisation for both
+            const bool with_records = first == 0;
+            if (with_records)
+                HIP_TRY(hipMemcpyAsync(vpls_out, d_out, (size_t)max_vpl_count * sizeof(VplRec), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
+            std::memcpy(&acc, ms->h_one, sizeof(Acc));
             if (acc.error) return fail(GIGL_ERR_INVALID, "a hit triangle names a material beyond n_mat");
-            if (acc.done) break;
+            if (acc.done) {
+                if (!with_records) {
+                    HIP_TRY(hipMemcpyAsync(vpls_out, d_out, (size_t)max_vpl_count * sizeof(VplRec), hipMemcpyDeviceToHost, st));
+                    HIP_TRY(hipStreamSynchronize(st));
+                }
+                break;
+            }
             first += nb;
         }
         if (!acc.done) {   // :181-184: not enough VPLs within 100 * max_vpl_count paths: the array is cleared
+            std::memset(vpls_out, 0, (size_t)max_vpl_count * sizeof(VplRec));   // what the first block's copy left there
             if (n_paths_out) *n_paths_out = (uint32_t)path_limit;
             return GIGL_OK;
         }
-        hipLaunchKernelGGL(vpl_normalize_kernel, dim3(((unsigned)max_vpl_count + 255u) / 256u), dim3(256), 0, st, d_out,
-                           (unsigned)max_vpl_count, acc.n_paths);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(vpls_out, d_out, (size_t)max_vpl_count * sizeof(VplRec), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
         *n_vpls_out = max_vpl_count;
         if (n_paths_out) *n_paths_out = acc.n_paths;
         return GIGL_OK;

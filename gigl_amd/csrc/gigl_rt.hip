@@ -927,6 +927,7 @@ namespace {
 struct ExtWorkspace {
     void* base;           // 256 bytes of counters, then the spill area
     unsigned max_grid;    // workgroups the spill area was sized for (kSpillDepth entries per lane)
+    bool counter_is_zero; // the caller's kernels on the same stream leave the work counter at zero: no memset
 };
 
 template <bool ANY, int GEN, int STACK_N, int BLOCK = kBlock>
@@ -968,7 +969,7 @@ int launch_trace_t(const gigl_scene* s, TraceParams& P, const Options& opt, hipS
         const size_t spill_entries = spill ? (size_t)grid * BLOCK * (size_t)(32 - STACK_N) : 0;
         HIP_TRY(gd::pool_alloc(s->device, &ws, 256 + spill_entries * sizeof(uint4), st));
     }
-    if (!P.reset_counter && hipMemsetAsync(ws, 0, 256, st) != hipSuccess) {
+    if (!P.reset_counter && !(ext && ext->counter_is_zero) && hipMemsetAsync(ws, 0, 256, st) != hipSuccess) {
         if (!ext) (void)hipFreeAsync(ws, st);
         return fail(GIGL_ERR_HIP, "hipMemsetAsync(workspace)");
     }
@@ -1114,8 +1115,12 @@ int check_batch(const gigl_scene* s, const void* a, const void* b, uint64_t n, c
 
 // Closest-hit batch that also leaves, per ray, the (t_min, t_max) KdTree::intersect ends with and the hit
 // triangle's record: what Scene::trace's callers read from the ray afterwards (gigl_photon.hip).
+size_t gd::trace_workspace_bytes(unsigned blocks) {
+    return 256 + (size_t)blocks * kBlock * kSpillDepth * sizeof(uint4);
+}
+
 int gd::trace_closest_ranges(const gigl_scene* s, const float4* o_tmin, const float4* d_tmax, unsigned n, uint4* hits,
-                             float2* ranges, float4* hit_tri, hipStream_t st) {
+                             float2* ranges, float4* hit_tri, hipStream_t st, void* ws, unsigned ws_blocks) {
     if (n == 0) return GIGL_OK;
     TraceParams P = {};
     P.n = n;
@@ -1124,6 +1129,10 @@ int gd::trace_closest_ranges(const gigl_scene* s, const float4* o_tmin, const fl
     P.hits = hits;
     P.ranges = ranges;
     P.hit_tri = hit_tri;
+    if (ws && ws_blocks) {
+        const ExtWorkspace ext = {ws, ws_blocks, true};
+        return launch_trace<false, 0>(s, P, st, &ext);
+    }
     return launch_trace<false, 0>(s, P, st);
 }
 
@@ -1610,7 +1619,7 @@ int gigl_trace_closest_noalloc_device(const gigl_scene* s, const void* o_tmin, c
     P.o_tmin = (const float4*)o_tmin;
     P.d_tmax = (const float4*)d_tmax;
     P.hits = (uint4*)hits;
-    const ExtWorkspace ext = {s->scratch, kNoAllocBlocks};
+    const ExtWorkspace ext = {s->scratch, kNoAllocBlocks, false};
     return launch_trace<false, 0>(s, P, (hipStream_t)stream, &ext);
 }
 
@@ -1669,7 +1678,7 @@ int gigl_trace_one(const gigl_scene* s, const float o[3], const float d[3], floa
     P.box = s->box;
     P.refill_thresh = 1; P.chunk = 64; P.t_exit = 1;
     opt.guided = 0; opt.stats = 0;
-    const ExtWorkspace ext = {s->one_ws, 1u};
+    const ExtWorkspace ext = {s->one_ws, 1u, false};
     int rc = launch_trace_t<false, 0, 8, 64>(s, P, opt, s->one_stream, &ext);
     if (rc != GIGL_OK) return rc;
     HIP_TRY(hipStreamSynchronize(s->one_stream));
