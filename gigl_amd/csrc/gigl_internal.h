@@ -238,7 +238,7 @@ struct TraceParams {
     unsigned long long* stats;   // STATS build only: 12 counters
     float2* ranges;              // optional: the ray's (t_min, t_max) as KdTree::intersect leaves them
     float4* hit_tri;             // optional, with ranges: the first 48 bytes of the hit triangle's record per ray
-    unsigned reset_counter;      // single-wave launches only: the wave zeroes the work counter on exit
+    unsigned reset_counter;      // kept workspaces: the last wave out zeroes the counter words (counter[0] work, counter[1] waves out)
     const unsigned* perm;        // optional (GEN 0): work item i traces ray perm[i] (ray regrouping)
 };
 

@@ -611,8 +611,16 @@ __global__ void __launch_bounds__(BLOCK) GIGL_WAVES_ATTR trace_kernel(const Trac
         const unsigned long long m = __ballot(occ);
         if (group_base != kMiss && lane == 0) P.bits[group_base >> 6] = m;
     }
-    // a single-wave launch (gigl_trace_one) leaves the work counter at zero for the next one
-    if (P.reset_counter && blockIdx.x == 0 && tid == 0) *P.counter = 0u;
+    // launches on a workspace that is kept (gigl_trace_one, the no-allocation entry point) leave the work counter
+    // at zero for the next one, so that no memset has to precede them (one that a HIP graph would have to replay):
+    // every wave checks out once it has taken its last request, and the last one out clears both words
+    if (P.reset_counter && lane == 0) {
+        const unsigned n_waves = gridDim.x * (BLOCK / 64);
+        if (atomicAdd(P.counter + 1, 1u) == n_waves - 1u) {
+            P.counter[1] = 0u;
+            P.counter[0] = 0u;
+        }
+    }
     if (STATS && lane == 0 && P.stats) {
         atomicAdd(P.stats + 0, (unsigned long long)st_rounds);
         atomicAdd(P.stats + 1, (unsigned long long)st_t_iters);
@@ -1619,6 +1627,7 @@ int gigl_trace_closest_noalloc_device(const gigl_scene* s, const void* o_tmin, c
     P.o_tmin = (const float4*)o_tmin;
     P.d_tmax = (const float4*)d_tmax;
     P.hits = (uint4*)hits;
+    P.reset_counter = 1u;   // the scratch array starts at zero and every launch leaves its counter words so: no memset
     const ExtWorkspace ext = {s->scratch, kNoAllocBlocks, false};
     return launch_trace<false, 0>(s, P, (hipStream_t)stream, &ext);
 }

@@ -140,7 +140,9 @@ int gigl_multi_trace_closest(gigl_multi* m, const float* o_tmin, const float* d_
  * 24 MiB array that is part of the library's device image (one copy per GPU, held until the process
  * ends), located once per device in gigl_scene_create.  The launch is held to 256 workgroups (one
  * per CU), which that array is sized for, so large batches run slower than through
- * gigl_trace_closest_device.  n > GIGL_NOALLOC_MAX_RAYS fails with GIGL_ERR_TOO_LARGE.  Every call on
+ * gigl_trace_closest_device.  The call enqueues one kernel launch and nothing else (each launch leaves the
+ * array's counter words at zero for the next), so it can be captured in a HIP graph and replayed.
+ * n > GIGL_NOALLOC_MAX_RAYS fails with GIGL_ERR_TOO_LARGE.  Every call on
  * a GPU shares that GPU's array: calls that overlap on one GPU (two streams, two host threads, two
  * scenes on the same device) RACE; issue them in stream order on one stream. */
 #define GIGL_NOALLOC_MAX_RAYS (1u << 24)

@@ -47,3 +47,49 @@ def test_noalloc_matches_allocating_entry_point(cornell):
     g.trace_closest_noalloc_device(0, 0, 0, 0, 0)   # empty batch: nothing to do
     g.close()
     gc.close()
+
+
+def test_noalloc_under_graph_capture(cornell):
+    """The callers the entry point is for: captured once in a HIP graph, replayed several times, and once more
+    after new rays were written into the same buffers.  Every replay equals gigl_trace_closest_device."""
+    torch = pytest.importorskip("torch")
+    V, T = synth.tessellate(cornell["verts"], cornell["tris"], 16)
+    g = rt.Scene(V, T, device=0, **S.KD_PARAMS)
+    n = 100_003
+    ro, rd = synth.bounce_rays(V, T, n, 0xC0FFEE)
+    d_o, d_d = torch.from_numpy(ro).cuda(), torch.from_numpy(rd).cuda()
+    want = torch.empty((n, 4), dtype=torch.int32, device="cuda:0")
+    out = torch.zeros((n, 4), dtype=torch.int32, device="cuda:0")
+
+    def reference():
+        g.trace_closest_device(d_o.data_ptr(), d_d.data_ptr(), n, want.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+
+    reference()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        g.trace_closest_noalloc_device(d_o.data_ptr(), d_d.data_ptr(), n, out.data_ptr(),
+                                       torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert bool((out == 0).all()), "capturing must not run the launch"
+    for it in range(3):
+        out.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, want), "replay %d" % it
+    ro2, rd2 = synth.bounce_rays(V, T, n, 0xC0FFEF)
+    d_o.copy_(torch.from_numpy(ro2))
+    d_d.copy_(torch.from_numpy(rd2))
+    reference()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want), "replay on new rays"
+    # and an ordinary call right after the replays finds the scratch as it expects it
+    out.zero_()
+    g.trace_closest_noalloc_device(d_o.data_ptr(), d_d.data_ptr(), n, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
+    del graph
+    g.close()
