@@ -87,3 +87,41 @@ def test_random_soup(seed, n_tris, scale, flavour, params):
     finally:
         rt.set_option("leaf_blocks", -1)
     ora.close()
+
+
+@pytest.mark.parametrize("flavour", ["bits", "one_component", "specials"])
+def test_rays_of_arbitrary_bit_patterns(cornell, flavour):
+    """Rays nobody would write: random bit patterns (NaN, infinities, denormals, huge values) in all or in one
+    of the eight ray words, or special values dropped into sane rays.  The traversal has to terminate and to
+    agree with the oracle: ids and occlusion bits exactly, t/u/v bit for bit or NaN on both sides."""
+    from gigl_amd import scene_io as S, synth
+    V, T = synth.tessellate(cornell["verts"], cornell["tris"], 16)
+    gpu = rt.Scene(V, T, device=0, **S.KD_PARAMS)
+    ora = O.OracleScene(V, T, **S.KD_PARAMS)
+    rng = np.random.default_rng(20261111)
+    n = 60_000
+    ro, rd = synth.bounce_rays(V, T, n, 0x6A7BA6E)
+    both = np.concatenate([ro, rd], 1)
+    rnd = lambda shape: rng.integers(0, 2 ** 32, shape, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    if flavour == "bits":
+        both = rnd((n, 8))
+    elif flavour == "one_component":
+        both[np.arange(n), rng.integers(0, 8, n)] = rnd(n)
+    else:
+        specials = np.array([np.nan, np.inf, -np.inf, 0.0, -0.0, 1e-45, -1e-45, 3.4e38, -3.4e38, 1e-38], np.float32)
+        for _ in range(2):
+            both[np.arange(n), rng.integers(0, 8, n)] = specials[rng.integers(0, len(specials), n)]
+    ro, rd = np.ascontiguousarray(both[:, :4]), np.ascontiguousarray(both[:, 4:])
+    with np.errstate(all="ignore"):
+        want = ora.trace_closest(ro, rd, n_threads=4)
+        occ = ora.trace_any(ro, rd, n_threads=4)
+    got = gpu.trace(ro, rd)
+    assert np.array_equal(got["tri_id"], want["tri_id"])
+    hit = got["tri_id"] != rt.GIGL_MISS
+    assert hit.sum() > (500 if flavour == "bits" else 5000)
+    for k in ("t", "u", "v"):
+        a, b = got[k][hit], want[k][hit]
+        assert bool(((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))).all()), k
+    assert np.array_equal(gpu.trace(ro, rd, is_vis_ray=True), occ.astype(bool))
+    gpu.close()
+    ora.close()
