@@ -1549,12 +1549,40 @@ struct HostPipe {
 };
 }  // namespace
 
+// A batch of one chunk: copy, trace, copy on the default stream, buffers from the pool.  Nothing to overlap,
+// and no streams or events to create (they cost 0.15 ms per call, more than a small batch takes).
+static int trace_host_small(const gigl_scene* s, const float* o_tmin, const float* d_tmax, uint64_t n, void* out, bool any) {
+    const size_t out_bytes = any ? (size_t)((n + 63) / 64 * 8) : (size_t)n * sizeof(gigl_hit);
+    void* d[3] = {nullptr, nullptr, nullptr};
+    auto release = [&]() {
+        for (void* p : d)
+            if (p) (void)hipFreeAsync(p, nullptr);
+    };
+    hipError_t e = gd::pool_alloc(s->device, &d[0], n * 16, nullptr);
+    if (e == hipSuccess) e = gd::pool_alloc(s->device, &d[1], n * 16, nullptr);
+    if (e == hipSuccess) e = gd::pool_alloc(s->device, &d[2], out_bytes, nullptr);
+    if (e == hipSuccess) e = hipMemcpyAsync(d[0], o_tmin, n * 16, hipMemcpyHostToDevice, nullptr);
+    if (e == hipSuccess) e = hipMemcpyAsync(d[1], d_tmax, n * 16, hipMemcpyHostToDevice, nullptr);
+    int rc = GIGL_OK;
+    if (e == hipSuccess)
+        rc = any ? gigl_trace_any_device(s, d[0], d[1], n, (uint64_t*)d[2], nullptr)
+                 : gigl_trace_closest_device(s, d[0], d[1], n, (gigl_hit*)d[2], nullptr);
+    if (e == hipSuccess && rc == GIGL_OK) e = hipMemcpyAsync(out, d[2], out_bytes, hipMemcpyDeviceToHost, nullptr);
+    const hipError_t se = hipStreamSynchronize(nullptr);   // also on failure: nothing may still use the buffers
+    release();
+    if (rc != GIGL_OK) return rc;
+    if (e == hipSuccess) e = se;
+    if (e != hipSuccess) return fail(GIGL_ERR_HIP, std::string("host-pointer batch: ") + hipGetErrorString(e));
+    return GIGL_OK;
+}
+
 static int trace_host(const gigl_scene* s, const float* o_tmin, const float* d_tmax, uint64_t n, void* out, bool any) {
     int rc = check_batch(s, o_tmin, d_tmax, n, out);
     if (rc != GIGL_OK || n == 0) return rc;
     DeviceGuard g(s->device);
     const bool piped = GIGL_HOST_PIPELINE && n > kHostChunk;
-    const uint64_t chunk = piped ? kHostChunk : n;
+    if (!piped) return trace_host_small(s, o_tmin, d_tmax, n, out, any);
+    const uint64_t chunk = kHostChunk;
     const uint64_t n_chunks = (n + chunk - 1) / chunk;
     const int S = (int)std::min<uint64_t>(kHostSlots, n_chunks);
     auto out_bytes = [&](uint64_t m) { return any ? (size_t)((m + 63) / 64 * 8) : (size_t)m * sizeof(gigl_hit); };
@@ -1565,7 +1593,7 @@ static int trace_host(const gigl_scene* s, const float* o_tmin, const float* d_t
         if (e_ != hipSuccess) return fail(GIGL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
     HOST_TRY(hipStreamCreateWithFlags(&hp.s_in, hipStreamNonBlocking));
-    for (int k = 0; k < (piped ? 2 : 1); ++k) HOST_TRY(hipStreamCreateWithFlags(&hp.s_cmp[k], hipStreamNonBlocking));
+    for (int k = 0; k < 2; ++k) HOST_TRY(hipStreamCreateWithFlags(&hp.s_cmp[k], hipStreamNonBlocking));
     for (int k = 0; k < S; ++k) {
         HOST_TRY(hipEventCreateWithFlags(&hp.ev_in[k], hipEventDisableTiming));
         HOST_TRY(hipEventCreateWithFlags(&hp.ev_k[k], hipEventDisableTiming));
@@ -1583,7 +1611,7 @@ static int trace_host(const gigl_scene* s, const float* o_tmin, const float* d_t
             HOST_TRY(hipMemcpyAsync(hp.d_o[slot], o_tmin + lo * 4, m * 16, hipMemcpyHostToDevice, hp.s_in));
             HOST_TRY(hipMemcpyAsync(hp.d_d[slot], d_tmax + lo * 4, m * 16, hipMemcpyHostToDevice, hp.s_in));
             HOST_TRY(hipEventRecord(hp.ev_in[slot], hp.s_in));
-            hipStream_t c = hp.s_cmp[piped ? (k & 1) : 0];
+            hipStream_t c = hp.s_cmp[k & 1];
             HOST_TRY(hipStreamWaitEvent(c, hp.ev_in[slot], 0));
             if (k >= (uint64_t)S) HOST_TRY(hipStreamWaitEvent(c, hp.ev_out[slot], 0));       // chunk k-S's records have left
             rc = any ? gigl_trace_any_device(s, hp.d_o[slot], hp.d_d[slot], m, (uint64_t*)hp.d_out[slot], c)
@@ -1595,7 +1623,7 @@ static int trace_host(const gigl_scene* s, const float* o_tmin, const float* d_t
             const int slot = (int)((k - 1) % (uint64_t)S);
             const uint64_t lo = (k - 1) * chunk, m = std::min(chunk, n - lo);
             char* dst = (char*)out + (any ? (size_t)(lo / 64 * 8) : (size_t)lo * sizeof(gigl_hit));
-            hipStream_t c = hp.s_cmp[piped ? ((k - 1) & 1) : 0];   // behind the chunk's traversal, in stream order
+            hipStream_t c = hp.s_cmp[(k - 1) & 1];   // behind the chunk's traversal, in stream order
             HOST_TRY(hipMemcpyAsync(dst, hp.d_out[slot], out_bytes(m), hipMemcpyDeviceToHost, c));
             HOST_TRY(hipEventRecord(hp.ev_out[slot], c));
         }
