@@ -126,6 +126,22 @@ def valu_roofline(key, units, k_ms):
         return None
 
 
+LINE_RATE_PEAK_G = 56.4   # L2-missing 128-byte lines per second one MI355X serves (profiles/r01_gather_lines.txt)
+
+
+def line_rate_info(traffic, traffic_src, n_rays, k_ms):
+    """The memory-side picture of a launch from the committed counter pass: bytes per second that cross the L2
+    (reads as 128-byte lines + writes) and the missing lines per second against the measured ceiling."""
+    if not traffic or not traffic_src or not traffic_src.get("tcc_miss_per_ray"):
+        return None
+    lines = traffic_src["tcc_miss_per_ray"] * n_rays / (k_ms * 1e-3) / 1e9
+    return {"gb_per_s": round(traffic / (k_ms * 1e-3) / 1e9, 1), "frac_of_hbm_peak": round(traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "l2_miss_g_lines_per_s": round(lines, 2), "line_rate_ceiling": LINE_RATE_PEAK_G,
+            "frac_of_line_rate": round(lines / LINE_RATE_PEAK_G, 4),
+            "note": "counter-pass constants x this run's kernel time; the ceiling is tools/micro/gather_lines.hip's "
+                    "(random 128-byte lines, from the Infinity Cache and from HBM alike)"}
+
+
 def kernel_name(layout, closest=True, gen="explicit rays"):
     return "trace_kernel<%s, %s, %s>" % ("triples" if layout == 2 else "pairs", "closest" if closest else "any", gen)
 
@@ -364,6 +380,9 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": traffic, "traffic_source": traffic_src,
+                         # what the memory system actually moves: the committed counter pass's bytes at this run's
+                         # kernel time, and its L2-missing lines against the chip's measured random-line rate
+                         "traffic_rate": line_rate_info(traffic, traffic_src, n, k_eff_ms),
                          "valu": valu_roofline("bounce" if tess == 158 else "bounce_s%d" % tess, n, k_eff_ms),
                          "kernel": kernel_name(layout), "kernel_ms": round(k_eff_ms, 4),
                          "pipelined": tracer.pipeline,

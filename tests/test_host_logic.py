@@ -222,6 +222,11 @@ def test_committed_counter_passes_feed_the_bench_lines():
         scaled, src2 = bench.traffic_from_profiles(key, 2, 1 << 27)
         assert abs(scaled - 8 * got) < 1e-3 * got and "scaled" in src2["note"]
         assert bench.traffic_from_profiles(key, 1, 1 << 24) == (None, None)     # another layout: no figure
+        k_ms = 6.0 if key == "bounce" else 10.0           # about what the launches take
+        lr = bench.line_rate_info(got, src, 1 << 24, k_ms)
+        assert 0.2 < lr["frac_of_line_rate"] < 1.0 and 0.2 < lr["frac_of_hbm_peak"] < 1.0
+        assert abs(lr["l2_miss_g_lines_per_s"] - e["tcc_miss_per_ray"] * (1 << 24) / (k_ms * 1e-3) / 1e9) < 0.01
+    assert bench.line_rate_info(None, None, 1, 1.0) is None
     for key in ("bounce", "bounce_s500", "cornell_shadow", "transmittance"):
         v = bench.valu_roofline(key, 1 << 24, 5.0)
         assert v and 0 < v["frac"] and v["peak"] == bench.VALU_PEAK_GINST
