@@ -218,6 +218,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    tracer.prime()   # N > 1: RCCL sets up its communicator on first use; not a step, and not timed
     for _ in range(args.warmup):
         tracer.step()
     barrier()

@@ -60,6 +60,21 @@ class ShardedTracer:
         self.pending = {}
         self.i = 0
 
+    def prime(self):
+        """One tiny gather outside any timed region: the backend sets up its communicator on first use (seconds
+        with RCCL), which would otherwise land in the first step of a run without warm-up steps."""
+        if not self.gather or self.dist is None:
+            return
+        dev = self.gathered[0].device if self.rank == 0 else (self.device if (self.overlap or not self.on_gpu) else self.torch.device("cpu"))
+        one = self.torch.zeros(4, dtype=self.torch.int32, device=dev)
+        into = [self.torch.zeros(4, dtype=self.torch.int32, device=dev) for _ in range(self.world)] if self.rank == 0 else None
+        if self.overlap:
+            with self.torch.cuda.stream(self.comm_stream):
+                self.dist.gather(one, into, dst=0)
+            self.torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
+        else:
+            self.dist.gather(one, into, dst=0)
+
     def step_stream(self, i=None):
         """The stream step i (default: the next one) traverses on; None on the CPU."""
         if not self.on_gpu:

@@ -42,6 +42,7 @@ for pipeline in (False, True):
     st = shard.ShardedTracer(torch, dist, 1, 0, n, torch.device("cuda", 0), trace_fn, gather=True, backend="nccl",
                              pipeline=pipeline, gather_when_alone=True)
     assert st.overlap and st.gather and st.pipeline == pipeline
+    st.prime()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     for i in range(steps):          # all steps in flight before anything is waited for
         st.step(events=ev[i])
