@@ -60,7 +60,45 @@ def parse():
     ap.add_argument("--sample-parity", dest="full_parity", action="store_false",
                     help="check only the CPU-timed sample against the oracle instead of the whole batch")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (gigl_set_option)")
+    ap.add_argument("--no-other-configs", dest="other_configs", action="store_false",
+                    help="N = 1 default workload: do not run the other BASELINE.json configurations after the timed "
+                         "loop (any-hit on the same batch, configs[1], configs[4], configs[0]; config.other_configs)")
     return ap.parse_args()
+
+
+def spawn_ranks(n):
+    """`bench.py --gpus N` without a launcher (WORLD_SIZE unset): N fresh child processes of this script, one per
+    rank, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set the way torch.distributed.run sets them.  Called
+    before anything has touched the GPU; the current process is never replaced, it waits for the children,
+    passes rank 0's line through (the children inherit stdout) and exits with the first non-zero code, after
+    ending the ranks that are still running."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GIGL_BENCH_SPAWNED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    live = list(procs)
+    while live and rc == 0:
+        time.sleep(0.05)
+        for p in list(live):
+            code = p.poll()
+            if code is not None:
+                live.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+    for p in live:   # a rank failed: the others would wait for it in a collective
+        p.terminate()
+    for p in live:
+        try:
+            p.wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            p.kill()
+    return rc
 
 
 def host_info(O=None):
@@ -86,14 +124,42 @@ def git_head():
         return None
 
 
+KERNEL_SOURCES = ["gigl_amd/csrc/gigl_rt.hip", "gigl_amd/csrc/gigl_internal.h", "gigl_amd/csrc/kd_layout.cpp",
+                  "gigl_amd/csrc/kd_layout.h"]
+
+
+def kernel_sources_hash():
+    """sha256 over the sources that decide what the traversal kernel executes and reads: the counter constants
+    in profiles/traffic.json are quoted only while this equals the hash stored with them (tools/traffic_hash.py)."""
+    import hashlib
+    h = hashlib.sha256()
+    try:
+        for rel in KERNEL_SOURCES:
+            h.update(open(os.path.join(ROOT, rel), "rb").read())
+    except OSError:
+        return None
+    return h.hexdigest()[:16]
+
+
+def traffic_json():
+    """profiles/traffic.json, or None when it is missing or was taken on other kernel sources than this tree's."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    except Exception:
+        return None, "profiles/traffic.json missing or unreadable"
+    want, have = tj.get("kernel_sources_sha256_16"), kernel_sources_hash()
+    if want is None or have is None or want != have:
+        return None, ("kernel sources changed since the counter passes in profiles/traffic.json were taken "
+                      "(stored %s, this tree %s): not quoted" % (want, have))
+    return tj, None
+
+
 def traffic_from_profiles(key, layout, n_rays=1 << 24):
     """HBM-side bytes per launch from the committed PMC passes (profiles/traffic.json), with where the
     number comes from: bench.py cannot collect counters itself, so this is NOT measured by this run."""
-    tp = os.path.join(ROOT, "profiles", "traffic.json")
-    try:
-        tj = json.load(open(tp))
-    except Exception:
-        return None, None
+    tj, why = traffic_json()
+    if tj is None:
+        return None, {"file": "profiles/traffic.json", "note": why}
     ent = tj.get(key) if isinstance(tj.get(key), dict) else None
     if ent is None and key == "bounce" and "trace_closest_hbm_bytes_per_launch" in tj:   # round-1 file
         ent = {"hbm_bytes_per_launch": tj["trace_closest_hbm_bytes_per_launch"], "layout": tj.get("layout"),
@@ -101,6 +167,7 @@ def traffic_from_profiles(key, layout, n_rays=1 << 24):
     if ent is None or (ent.get("layout") is not None and ent.get("layout") != layout):
         return None, None
     src = {"file": "profiles/traffic.json", "from": ent.get("source"), "commit": ent.get("commit"),
+           "kernel_sources_sha256_16": tj.get("kernel_sources_sha256_16"),
            "fetch_size_bytes": ent.get("fetch_size_bytes"), "tcc_miss_per_ray": ent.get("tcc_miss_per_ray"),
            "note": "constant from a committed rocprofv3 --pmc pass of the same command, not measured by this run"}
     b = ent.get("hbm_bytes_per_launch")
@@ -114,7 +181,8 @@ def valu_roofline(key, units, k_ms):
     """Vector-ALU issue roofline of a kernel that is bound by it: wave instructions per unit from a committed
     counter pass (profiles/traffic.json) x the units of this run / the kernel time of this run."""
     try:
-        ent = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(key)
+        tj, _ = traffic_json()
+        ent = tj.get(key) if tj else None
         if not ent:
             return None
         ginst = ent["valu_insts_per_pair"] * units / (k_ms * 1e-3) / 1e9
@@ -150,9 +218,15 @@ def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args.gpus))   # no launcher: this process becomes the launcher
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+    if world != args.gpus:   # never a silent single-GPU number under an N-GPU label, or the reverse
+        raise SystemExit("WORLD_SIZE %d != --gpus %d: launch with `python -m torch.distributed.run --nproc-per-node %d "
+                         "bench.py --gpus %d`, or plain `python bench.py --gpus %d` (it starts its own ranks)"
+                         % (world, args.gpus, args.gpus, args.gpus, args.gpus))
     import torch
     import torch.distributed as dist
     from gigl_amd import rt, scene_io as S, shard, synth
@@ -165,6 +239,8 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    if world > 1:   # the ranks of a node share its cores: each builds (and generates rays) on its share
+        rt.set_option("build_threads", max(1, min(16, (os.cpu_count() or 1) // world)))
     for kv in args.opt:
         k, v = kv.split("=")
         rt.set_option(k, int(v))
@@ -299,7 +375,7 @@ def main():
         # size-independent sanity at full size: every reported hit lies inside its ray's range
         hit_mask = hits["tri_id"] != rt.GIGL_MISS
         assert (hits["tri_id"][hit_mask] < len(T)).all() and (hits["t"][hit_mask] > 0).all()
-        cpu = parity = bytes_per_ray = mean_nodes = mean_tris = None
+        cpu = parity = bytes_per_ray = mean_nodes = mean_tris = ora = None
         counters_from = None
         hinfo = host_info()
         if not args.no_cpu_baseline:
@@ -398,6 +474,9 @@ def main():
         }
         if args.extras and world == 1:
             out["extras"] = extras(torch, rt, S, scene, d_o, d_d, n, device)
+        if args.other_configs and world == 1:
+            out["config"]["other_configs"] = other_configs(args, torch, rt, S, device, scene, ora, d_o, d_d, ro, rd, n,
+                                                           layout, hits)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
@@ -421,11 +500,14 @@ def cornell_inputs(torch, rt, S, device):
     return dict(verts=cv, tris=ct, mats=mats, scene=cs, cam=cam, vpls=vp, lights=lights, dens=dens, box=box, fog=fog)
 
 
-def cornell_config(args, torch, rt, S, device):
-    """configs[1] (cornell_shadow) and configs[4] (transmittance) as driver-runnable lines."""
+def cornell_config(args, torch, rt, S, device, ci=None):
+    """configs[1] (cornell_shadow) and configs[4] (transmittance) as driver-runnable lines.  ci: inputs shared
+    with the caller's other Cornell configurations (then they stay open)."""
     from oracle import oracle_py as O
     t0 = time.time()
-    ci = cornell_inputs(torch, rt, S, device)
+    own_ci = ci is None
+    if own_ci:
+        ci = cornell_inputs(torch, rt, S, device)
     cs, cam, lights, fog = ci["scene"], ci["cam"], ci["lights"], ci["fog"]
     nl = len(lights)
     npix = 1024 * 1024
@@ -591,17 +673,20 @@ def cornell_config(args, torch, rt, S, device):
             "transmittance_all_pairs_ms": round(timeit(lambda: cs.shadow_batch_device(*args_, None, fog=fog, transm_ptr=tr2.data_ptr(), stream=sh)), 3),
             "fused_bits_and_visible_transmittance_ms": round(timeit(lambda: cs.shadow_batch_fused_device(*args_, bits.data_ptr(), fog, tr2.data_ptr(), stream=sh)), 3),
             "occluded_fraction": round(float(rt.unpack_bits(bits.cpu().numpy().view(np.uint64), npair).sum()) / max(nhit * nl, 1), 4)}
-    fog.close()
-    cs.close()
+    if own_ci:
+        fog.close()
+        cs.close()
     return out
 
 
-def vpl_config(args, torch, rt, S, device):
+def vpl_config(args, torch, rt, S, device, ci=None):
     """configs[0]: VPL generation for the Cornell box's primary light as ray batches.  A step is one whole set
     (paths walked in blocks: one closest-hit batch per bounce, one lane per path, then the ordered gather)."""
     from oracle import oracle_py as O
     t0 = time.time()
-    ci = cornell_inputs(torch, rt, S, device)
+    own_ci = ci is None
+    if own_ci:
+        ci = cornell_inputs(torch, rt, S, device)
     cs, fog, mats = ci["scene"], ci["fog"], ci["mats"]
     n_vpls = args.vpls or S.MAX_N_VPLS
     call = lambda seed: cs.photon_trace_batch(mats, fog, S.ABS_K, S.SCA_K, S.MAJ_EXT_K, 1, S.PRIM_PL_POS,
@@ -648,9 +733,93 @@ def vpl_config(args, torch, rt, S, device):
                         "note": "launch-latency bound at this size: a set is ~12 launches over a few hundred to a few "
                                 "thousand paths and one 16-byte read-back per block of paths; no bandwidth figure applies"},
            "cpu_baseline": cpu, "parity": parity, "host": hinfo}
-    fog.close()
-    cs.close()
+    if own_ci:
+        fog.close()
+        cs.close()
     return out
+
+
+def any_hit_same_batch(args, torch, rt, scene, ora, d_o, d_d, ro, rd, n, device, layout, closest_hits):
+    """The other half of BASELINE.json's metric on the bench batch: the same rays as any-hit (occlusion) rays,
+    KdTree.hpp:328.  Timed like the headline (K launches on one stream, HIP events around each), checked against the
+    oracle's any-hit walk on the CPU-timed sample and — every ray — against the closest-hit records of the timed run
+    (a ray is occluded exactly when it has a closest hit: both walks accept the same first leaf)."""
+    stream = torch.cuda.current_stream()
+    sh = stream.cuda_stream
+    bits = torch.zeros((n + 63) // 64, dtype=torch.int64, device=device)
+    call = lambda: scene.trace_any_device(d_o.data_ptr(), d_d.data_ptr(), n, bits.data_ptr(), sh)
+    for _ in range(max(args.warmup, 1)):
+        call()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:   # the events bracket the bit array's clearing too: it is part of the call
+        a.record(stream)
+        call()
+        b.record(stream)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    k_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    got = rt.unpack_bits(bits.cpu().numpy().view(np.uint64), n)
+    parity = {"rays_checked_against_closest_hit_records": int(n),
+              "bit_mismatches_vs_closest_hit": int((got.astype(bool) != (closest_hits["tri_id"] != rt.GIGL_MISS)).sum())}
+    cpu = roof = None
+    if ora is not None:
+        cores = min(16, os.cpu_count() or 1)
+        nm = min(n, 1 << 21)
+        t1 = time.perf_counter()
+        want, cnt = ora.trace_any(ro[:nm], rd[:nm], counters=True, n_threads=cores)
+        cpu_s = time.perf_counter() - t1
+        parity["rays_checked_against_oracle"] = int(nm)
+        parity["bit_mismatches"] = int((got[:nm].astype(bool) != want.astype(bool)).sum())
+        nodes, tests = float(cnt[:, 0].mean()), float(cnt[:, 1].mean())
+        bpr = 32.0 + 0.125 + 8.0 * nodes + 56.0 * tests   # SURVEY.md §8(d): ray in, one bit out, nodes, triangle tests
+        ach = bpr * n / (k_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "kernel": kernel_name(layout, False),
+                "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_ray": round(bpr, 2), "mean_nodes_visited": nodes,
+                "mean_triangle_tests": tests, "counters_source": "oracle any-hit counters on the first 2^%d rays" % int(np.log2(nm))}
+        cpu = {"value": round(nm / cpu_s / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+               "sample": "first 2^%d rays of the same batch as any-hit rays, OpenMP over rays on %d threads" % (int(np.log2(nm)), cores)}
+    return {"metric": "Mrays/s (incoherent shadow any-hit)", "value": round(n * args.steps / elapsed / 1e6, 3), "unit": "Mrays/s",
+            "steps": args.steps, "ms_per_step": round(elapsed * 1e3 / args.steps, 4),
+            "config": {"workload": "the bench batch (%d rays) traced as any-hit rays, one bit per ray" % n},
+            "roofline": roof, "cpu_baseline": cpu, "parity": parity}
+
+
+def compact(j):
+    """An embedded configuration's line without what the enclosing line already says."""
+    drop = {"n_gpus", "warmup", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "host"}
+    out = {k: v for k, v in j.items() if k not in drop}
+    if isinstance(out.get("cpu_baseline"), dict):
+        out["cpu_baseline"] = {k: v for k, v in out["cpu_baseline"].items() if k not in ("omp_get_max_threads", "cpu_model", "threads_used")}
+    if isinstance(out.get("config"), dict):
+        out["config"] = {k: v for k, v in out["config"].items() if k not in ("commit", "setup_s", "device_layout")}
+    return out
+
+
+def other_configs(args, torch, rt, S, device, scene, ora, d_o, d_d, ro, rd, n, layout, closest_hits):
+    """Outside the timed loop of the default line: the rest of BASELINE.json's metric and configurations, each with
+    its own rate, kernel time, bound, cpu_baseline on a bounded sample and parity — so that the one line the driver
+    runs carries the whole metric (closest-hit AND shadow any-hit) and every configuration."""
+    res = {}
+    t0 = time.time()
+    res["any_hit_same_batch"] = any_hit_same_batch(args, torch, rt, scene, ora, d_o, d_d, ro, rd, n, device, layout, closest_hits)
+    ci = cornell_inputs(torch, rt, S, device)
+    sub = argparse.Namespace(steps=args.steps, warmup=max(args.warmup, 1), no_cpu_baseline=args.no_cpu_baseline,
+                             extras=False, vpls=None, config=None)
+    for name, key in (("cornell_shadow", "configs[1]"), ("transmittance", "configs[4]")):
+        sub.config = name
+        res[key] = compact(cornell_config(sub, torch, rt, S, device, ci=ci))
+    sub.config = "vpl"
+    res["configs[0]"] = compact(vpl_config(sub, torch, rt, S, device, ci=ci))
+    ci["fog"].close()
+    ci["scene"].close()
+    res["seconds"] = round(time.time() - t0, 1)
+    res["note"] = ("run after the timed loop of the headline configuration, on the same GPU, same --steps/--warmup; "
+                   "every entry is timed like the headline (wall clock around K synchronised steps, HIP events around "
+                   "the dominant kernel)")
+    return res
 
 
 def extras(torch, rt, S, scene, d_o, d_d, n, device):

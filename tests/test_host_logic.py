@@ -222,6 +222,7 @@ def test_committed_counter_passes_feed_the_bench_lines():
         scaled, src2 = bench.traffic_from_profiles(key, 2, 1 << 27)
         assert abs(scaled - 8 * got) < 1e-3 * got and "scaled" in src2["note"]
         assert bench.traffic_from_profiles(key, 1, 1 << 24) == (None, None)     # another layout: no figure
+        assert src["kernel_sources_sha256_16"] == bench.kernel_sources_hash() == t["kernel_sources_sha256_16"]
         k_ms = 6.0 if key == "bounce" else 10.0           # about what the launches take
         lr = bench.line_rate_info(got, src, 1 << 24, k_ms)
         assert 0.2 < lr["frac_of_line_rate"] < 1.0 and 0.2 < lr["frac_of_hbm_peak"] < 1.0
@@ -232,3 +233,56 @@ def test_committed_counter_passes_feed_the_bench_lines():
         assert v and 0 < v["frac"] and v["peak"] == bench.VALU_PEAK_GINST
         assert os.path.exists(os.path.join(ROOT, v["source"].split()[0])), v["source"]
     assert bench.valu_roofline("no such entry", 1, 1.0) is None
+    # counter constants are quoted only for the kernel sources they were taken on
+    real = bench.kernel_sources_hash
+    try:
+        bench.kernel_sources_hash = lambda: "0" * 16
+        got, src = bench.traffic_from_profiles("bounce", 2, 1 << 24)
+        assert got is None and "changed" in src["note"]
+        assert bench.valu_roofline("bounce", 1 << 24, 5.0) is None
+    finally:
+        bench.kernel_sources_hash = real
+
+
+def test_bench_refuses_a_world_that_is_not_gpus():
+    """bench.py --gpus N under a launcher that started another number of ranks is an error in every case: never a
+    single-GPU number under an N-GPU label (the check runs before torch or the engine are imported)."""
+    import subprocess
+    import sys
+    bench = os.path.join(ROOT, "bench.py")
+    for gpus, world in ((8, 1), (1, 2), (4, 8)):
+        env = dict(os.environ, WORLD_SIZE=str(world), RANK="0", LOCAL_RANK="0")
+        p = subprocess.run([sys.executable, bench, "--gpus", str(gpus)], env=env, capture_output=True, text=True, timeout=60)
+        assert p.returncode != 0 and "WORLD_SIZE %d != --gpus %d" % (world, gpus) in p.stderr, p.stderr[-500:]
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """bench.py --gpus N without a launcher starts N children with RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set and
+    returns the first failing rank's code.  Here the children fail early (no GPU in this container), which is
+    what is checked: N children ran, each saw its own rank and the common world, and the failure came back."""
+    import subprocess
+    import sys
+    import textwrap
+    spy = tmp_path / "sitecustomize.py"
+    spy.write_text(textwrap.dedent("""
+        import os
+        if os.environ.get("GIGL_BENCH_SPAWNED"):
+            open(os.path.join(os.environ["SPY_DIR"], "rank%s" % os.environ["RANK"]), "w").write(
+                " ".join(os.environ[k] for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")))
+    """))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(PYTHONPATH=str(tmp_path) + os.pathsep + env.get("PYTHONPATH", ""), SPY_DIR=str(tmp_path),
+               GIGL_BENCH_BACKEND="gloo")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--tess", "2", "--total-rays-log2", "8",
+                        "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=240)
+    seen = sorted(f for f in os.listdir(tmp_path) if f.startswith("rank"))
+    assert seen == ["rank0", "rank1", "rank2"], (seen, p.stderr[-800:])
+    ports = set()
+    for r in range(3):
+        rank, local, world, addr, port = (tmp_path / ("rank%d" % r)).read_text().split()
+        assert (int(rank), int(local), int(world), addr) == (r, r, 3, "127.0.0.1")
+        ports.add(port)
+    assert len(ports) == 1
+    import torch
+    if not torch.cuda.is_available():
+        assert p.returncode != 0   # no device here: the ranks fail, and the launcher says so

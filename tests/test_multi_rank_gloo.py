@@ -45,9 +45,10 @@ def _worker(rank, world, port, n, out_path):
     step_no = [0]
 
     def trace_fn(buf):                                # the tracer is injected: here the oracle stands in for the GPU
-        ro, rd = _batch(synth, V, T, n, step_no[0], first=lo, count=hi - lo)   # this rank's shard only
-        hits = ora.trace_closest(ro, rd)
-        buf[: hi - lo] = torch.from_numpy(hits.view(np.int32).reshape(-1, 4).copy())
+        if hi > lo:
+            ro, rd = _batch(synth, V, T, n, step_no[0], first=lo, count=hi - lo)   # this rank's shard only
+            hits = ora.trace_closest(ro, rd)
+            buf[: hi - lo] = torch.from_numpy(hits.view(np.int32).reshape(-1, 4).copy())
         step_no[0] += 1
 
     # the same class bench.py drives with the HIP engine and RCCL
@@ -71,13 +72,15 @@ def _worker(rank, world, port, n, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n", [4099, 64])
-def test_sharded_trace_and_gather_equals_single_batch(tmp_path, n):
+@pytest.mark.parametrize("n,world", [(4099, 2), (64, 2), (1003, 8), (5, 8)])
+def test_sharded_trace_and_gather_equals_single_batch(tmp_path, n, world):
+    """world 8 is the node bench.py is launched on: ragged ranges (1003 = 8 x 125 + 3), and fewer rays than
+    ranks (three ranks with an empty range)."""
     import torch.multiprocessing as mp
     from gigl_amd import scene_io as S, synth
     from oracle import oracle_py as O
     out = str(tmp_path / "gathered.npy")
-    mp.spawn(_worker, args=(2, _free_port(), n, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), n, out), nprocs=world, join=True)
     got = np.load(out).view(np.uint32)
     cv, ct, _, _ = S.load_obj(os.path.join(ROOT, "tests", "golden", "cornell_box.obj"))
     V, T = synth.tessellate(cv, ct, 4)
