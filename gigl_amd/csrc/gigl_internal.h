@@ -288,7 +288,8 @@ struct gigl_scene {
     float4* d_tris = nullptr;
     unsigned blocks_off8 = 0;      // leaf triangle blocks (kd_layout.h) start here in d_tris, in 8-byte units (0: none)
     size_t nb_nodes = 0, nb_leaf = 0, nb_tris = 0;   // bytes of the three device arrays
-    bool replica = false;          // a copy made by scene_clone_to_device: tree.nodes / leaf_prim_ids are empty
+    bool replica = false;          // a copy made by scene_clone_to_device / adopted from a device blob: no host tree
+    bool counted = false;          // counted among the device's scenes (the last one to go trims the library's pool)
     gd::BoxF box;
     gigl_tree_stats stats;
     int layout = 2;                // device layout in use (kd_layout.h): 0, 1 or 2 (2 may fall back to 1 at create)
@@ -336,6 +337,9 @@ size_t trace_workspace_bytes(unsigned blocks);
 
 // gigl_rt.hip: stream-ordered allocation from the library's own pool on `device` (release with hipFreeAsync)
 hipError_t pool_alloc(int device, void** p, size_t bytes, hipStream_t st);
+hipError_t pool_trim(int device);
+void scene_count(int device, int delta);
+extern std::atomic<unsigned long long> g_pool_allocs;
 
 struct DeviceGuard {
     int prev = -1;

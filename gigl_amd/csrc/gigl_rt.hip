@@ -897,6 +897,8 @@ namespace gd {
 // once that free has completed.
 std::mutex g_pool_mu;
 hipMemPool_t g_pool[kMaxDevices] = {nullptr};
+std::atomic<unsigned long long> g_pool_allocs{0};   // gigl_debug_pool_allocs: what a no-allocation call must leave unchanged
+int g_scenes_on_device[kMaxDevices] = {0};          // under g_pool_mu: the last scene to go trims the pool
 
 hipError_t pool_alloc(int device, void** p, size_t bytes, hipStream_t st) {
     *p = nullptr;
@@ -926,7 +928,28 @@ hipError_t pool_alloc(int device, void** p, size_t bytes, hipStream_t st) {
         }
         pool = g_pool[device];
     }
+    g_pool_allocs.fetch_add(1, std::memory_order_relaxed);
     return hipMallocFromPoolAsync(p, bytes, pool, st);
+}
+
+// Returns the memory the pool holds but no allocation uses to the device (the pool keeps the largest workspaces
+// a process ever asked for between calls: regrouping buffers, the pi-density hit buffer, the shadow point
+// cache, the host-pointer pipeline's slots).
+hipError_t pool_trim(int device) {
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    if (!g_pool[device]) return hipSuccess;
+    return hipMemPoolTrimTo(g_pool[device], 0);
+}
+void scene_count(int device, int delta) {
+    if (device < 0 || device >= kMaxDevices) return;
+    bool trim = false;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        g_scenes_on_device[device] += delta;
+        trim = delta < 0 && g_scenes_on_device[device] <= 0;
+    }
+    if (trim) (void)pool_trim(device);
 }
 }  // namespace gd
 namespace {
@@ -1106,7 +1129,9 @@ int scene_device_resources(gigl_scene* s) {
     HIP_TRY(hipMalloc(&s->one_ws, one_ws_bytes));
     HIP_TRY(hipMemset(s->one_ws, 0, 256));
     HIP_TRY(hipStreamCreateWithFlags(&s->one_stream, hipStreamNonBlocking));
-    return scratch_for_device(s->device, &s->scratch);
+    const int rc = scratch_for_device(s->device, &s->scratch);
+    if (rc == GIGL_OK) { s->counted = true; gd::scene_count(s->device, +1); }
+    return rc;
 }
 
 int check_batch(const gigl_scene* s, const void* a, const void* b, uint64_t n, const void* out) {
@@ -1210,6 +1235,7 @@ int gigl_device_count(int* count) {
 
 int gigl_debug_check_layout(const gigl_scene* s, int layout, int treelet_levels, uint64_t* bytes_out) {
     if (!s) return fail(GIGL_ERR_INVALID, "scene is NULL");
+    if (s->replica) return fail(GIGL_ERR_INVALID, "a scene adopted from device arrays has no host tree to check against");
     if (layout < 0 || layout > 3 || treelet_levels < 1 || treelet_levels > 5) return fail(GIGL_ERR_INVALID, "bad layout");
     gigl::DeviceTree dt;
     if (layout == 3) dt.leaf_block_min = 2;   // layout 2 with leaf triangle blocks
@@ -1448,6 +1474,86 @@ int gigl_scene_create(const float* verts, uint32_t n_verts, const uint32_t* tris
     return GIGL_OK;
 }
 
+int gigl_scene_export_device_blob(const gigl_scene* s, gigl_scene_blob* desc, void* ptrs_out[3]) {
+    if (!s || !desc) return fail(GIGL_ERR_INVALID, "NULL argument");
+    if (s->device == GIGL_DEVICE_NONE) return fail(GIGL_ERR_NO_DEVICE, "host-only scene: nothing on a device to export");
+    memset(desc, 0, sizeof(*desc));
+    desc->magic = GIGL_BLOB_MAGIC;
+    desc->version = 1;
+    desc->nb_nodes = s->nb_nodes; desc->nb_leaf_ids = s->nb_leaf; desc->nb_tris = s->nb_tris;
+    desc->layout = (uint32_t)s->layout; desc->triples = s->triples ? 1u : 0u;
+    desc->blocks_off8 = s->blocks_off8; desc->n_tris = s->n_tris;
+    desc->root[0] = s->root.x; desc->root[1] = s->root.y;
+    desc->root_rec[0] = s->root_rec.x; desc->root_rec[1] = s->root_rec.y;
+    desc->root_rec[2] = s->root_rec.z; desc->root_rec[3] = s->root_rec.w;
+    for (int a = 0; a < 3; ++a) { desc->box[a] = s->tree.box_min[a]; desc->box[3 + a] = s->tree.box_max[a]; }
+    desc->stats = s->stats;
+    if (ptrs_out) { ptrs_out[0] = s->d_nodes; ptrs_out[1] = s->d_leaf_ids; ptrs_out[2] = s->d_tris; }
+    return GIGL_OK;
+}
+
+int gigl_scene_create_from_device_blob(const gigl_scene_blob* desc, const void* nodes, const void* leaf_ids,
+                                       const void* tris, int device, void* stream, gigl_scene** out) {
+    if (!out) return fail(GIGL_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!desc || desc->magic != GIGL_BLOB_MAGIC || desc->version != 1) return fail(GIGL_ERR_INVALID, "not a scene blob of this library version");
+    if (!nodes || !tris || (desc->nb_leaf_ids && !leaf_ids)) return fail(GIGL_ERR_INVALID, "NULL array pointer");
+    // what the kernels assume of the arrays: at least the root's two slots, whole 8-byte node words, a triangle
+    // table of 64-byte records for n_tris triangles in front of the leaf blocks, layouts 0..2
+    if (desc->nb_nodes < 16 || desc->nb_nodes % 8 || desc->layout > 2u || (desc->triples != 0u) != (desc->layout == 2u) ||
+        desc->nb_tris < (uint64_t)desc->n_tris * 4 * kTriStride * 4 || (uint64_t)desc->blocks_off8 * 8 > desc->nb_tris ||
+        desc->stats.actual_depth < 0 || desc->stats.actual_depth > 64)
+        return fail(GIGL_ERR_INVALID, "inconsistent scene blob header");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+        return fail(GIGL_ERR_NO_DEVICE, "no HIP device: the engine has no CPU fallback");
+    if (device < 0 || device >= n_dev) return fail(GIGL_ERR_INVALID, "device index out of range");
+    gigl_scene* s = new gigl_scene();
+    s->device = device;
+    s->replica = true;
+    s->n_tris = desc->n_tris;
+    for (int a = 0; a < 3; ++a) { s->tree.box_min[a] = desc->box[a]; s->tree.box_max[a] = desc->box[3 + a]; }
+    s->tree.max_depth = desc->stats.max_depth; s->tree.actual_depth = desc->stats.actual_depth;
+    s->tree.leaf_count = desc->stats.leaf_count;
+    s->root = make_uint2(desc->root[0], desc->root[1]);
+    s->root_rec = make_uint4(desc->root_rec[0], desc->root_rec[1], desc->root_rec[2], desc->root_rec[3]);
+    s->triples = desc->triples != 0u; s->layout = (int)desc->layout;
+    s->box = BoxF{desc->box[0], desc->box[1], desc->box[2], desc->box[3], desc->box[4], desc->box[5]};
+    s->stats = desc->stats;
+    s->nb_nodes = desc->nb_nodes; s->nb_leaf = desc->nb_leaf_ids; s->nb_tris = desc->nb_tris;
+    s->blocks_off8 = desc->blocks_off8;
+    DeviceGuard g(device);
+    auto cleanup = [&]() {
+        if (s->d_nodes) (void)hipFree(s->d_nodes);
+        if (s->d_leaf_ids) (void)hipFree(s->d_leaf_ids);
+        if (s->d_tris) (void)hipFree(s->d_tris);
+        if (s->h_one) (void)hipHostFree(s->h_one);
+        if (s->one_ws) (void)hipFree(s->one_ws);
+        if (s->one_stream) (void)hipStreamDestroy(s->one_stream);
+        delete s;
+    };
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = g.ok ? hipSuccess : hipErrorInvalidDevice;
+    hipDeviceProp_t prop;
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
+    if (e == hipSuccess) s->n_cus = prop.multiProcessorCount;
+    if (e == hipSuccess) e = hipMalloc((void**)&s->d_nodes, s->nb_nodes);
+    if (e == hipSuccess && s->nb_leaf) e = hipMalloc((void**)&s->d_leaf_ids, s->nb_leaf);
+    if (e == hipSuccess) e = hipMalloc((void**)&s->d_tris, s->nb_tris);
+    if (e == hipSuccess) e = hipMemcpyAsync(s->d_nodes, nodes, s->nb_nodes, hipMemcpyDefault, st);
+    if (e == hipSuccess && s->nb_leaf) e = hipMemcpyAsync(s->d_leaf_ids, leaf_ids, s->nb_leaf, hipMemcpyDefault, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(s->d_tris, tris, s->nb_tris, hipMemcpyDefault, st);
+    const hipError_t se = hipStreamSynchronize(st);   // the caller may free its arrays when this returns
+    if (e == hipSuccess) e = se;
+    if (e != hipSuccess) {
+        cleanup();
+        return fail(GIGL_ERR_HIP, std::string("scene from device blob: ") + hipGetErrorString(e));
+    }
+    if (scene_device_resources(s) != GIGL_OK) { cleanup(); return GIGL_ERR_HIP; }
+    *out = s;
+    return GIGL_OK;
+}
+
 int gigl_scene_destroy(gigl_scene* s) {
     if (!s) return GIGL_OK;
     if (s->device == GIGL_DEVICE_NONE) { delete s; return GIGL_OK; }
@@ -1460,7 +1566,23 @@ int gigl_scene_destroy(gigl_scene* s) {
     (void)hipFree(s->one_ws);
     (void)hipFree(s->photon_ws);
     if (s->one_stream) (void)hipStreamDestroy(s->one_stream);
+    if (s->counted) gd::scene_count(s->device, -1);   // the last scene on a device returns the pool's idle memory
     delete s;
+    return GIGL_OK;
+}
+
+int gigl_trim_pool(int device) {
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return fail(GIGL_ERR_NO_DEVICE, "no HIP device");
+    if (device < 0 || device >= n_dev) return fail(GIGL_ERR_INVALID, "device index out of range");
+    DeviceGuard g(device);
+    HIP_TRY(gd::pool_trim(device));
+    return GIGL_OK;
+}
+
+int gigl_debug_pool_allocs(uint64_t* count) {
+    if (!count) return fail(GIGL_ERR_INVALID, "count is NULL");
+    *count = gd::g_pool_allocs.load(std::memory_order_relaxed);
     return GIGL_OK;
 }
 
@@ -1478,6 +1600,7 @@ int gigl_scene_stats(const gigl_scene* s, gigl_tree_stats* out) {
 
 int gigl_scene_export_tree(const gigl_scene* s, uint32_t* nodes_words, uint32_t* leaf_prim_ids) {
     if (!s) return fail(GIGL_ERR_INVALID, "scene is NULL");
+    if (s->replica) return fail(GIGL_ERR_INVALID, "a scene adopted from device arrays has no host tree to export");
     if (nodes_words && !s->tree.nodes.empty()) memcpy(nodes_words, s->tree.nodes.data(), s->tree.nodes.size() * 8);
     if (leaf_prim_ids && !s->tree.leaf_prim_ids.empty())
         memcpy(leaf_prim_ids, s->tree.leaf_prim_ids.data(), s->tree.leaf_prim_ids.size() * 4);
@@ -1549,26 +1672,49 @@ struct HostPipe {
 };
 }  // namespace
 
-// A batch of one chunk: copy, trace, copy on the default stream, buffers from the pool.  Nothing to overlap,
-// and no streams or events to create (they cost 0.15 ms per call, more than a small batch takes).
+// A batch of one chunk: copy, trace, copy on one stream, buffers from the pool.  Nothing to overlap, and no
+// streams or events to create per call (they cost 0.15 ms, more than a small batch takes): the stream is the
+// calling thread's own for the device, created on first use and kept.  (Not the null stream: it would order the
+// call against every blocking stream of the process, serialise calls from two host threads, and break a stream
+// capture in progress on another thread.)
+namespace {
+// Never destroyed: a thread's exit (the main thread's: process exit) may come after the HIP runtime has shut down.
+struct ThreadStreams {
+    hipStream_t st[kMaxDevices] = {nullptr};
+};
+hipError_t thread_stream(int device, hipStream_t* out) {
+    static thread_local ThreadStreams ts;
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    if (!ts.st[device]) {
+        const hipError_t e = hipStreamCreateWithFlags(&ts.st[device], hipStreamNonBlocking);
+        if (e != hipSuccess) return e;
+    }
+    *out = ts.st[device];
+    return hipSuccess;
+}
+}  // namespace
+
 static int trace_host_small(const gigl_scene* s, const float* o_tmin, const float* d_tmax, uint64_t n, void* out, bool any) {
     const size_t out_bytes = any ? (size_t)((n + 63) / 64 * 8) : (size_t)n * sizeof(gigl_hit);
+    hipStream_t st = nullptr;
+    hipError_t e = thread_stream(s->device, &st);
+    if (e != hipSuccess) return fail(GIGL_ERR_HIP, std::string("host-pointer batch: ") + hipGetErrorString(e));
     void* d[3] = {nullptr, nullptr, nullptr};
     auto release = [&]() {
         for (void* p : d)
-            if (p) (void)hipFreeAsync(p, nullptr);
+            if (p) (void)hipFreeAsync(p, st);
     };
-    hipError_t e = gd::pool_alloc(s->device, &d[0], n * 16, nullptr);
-    if (e == hipSuccess) e = gd::pool_alloc(s->device, &d[1], n * 16, nullptr);
-    if (e == hipSuccess) e = gd::pool_alloc(s->device, &d[2], out_bytes, nullptr);
-    if (e == hipSuccess) e = hipMemcpyAsync(d[0], o_tmin, n * 16, hipMemcpyHostToDevice, nullptr);
-    if (e == hipSuccess) e = hipMemcpyAsync(d[1], d_tmax, n * 16, hipMemcpyHostToDevice, nullptr);
+    e = gd::pool_alloc(s->device, &d[0], n * 16, st);
+    if (e == hipSuccess) e = gd::pool_alloc(s->device, &d[1], n * 16, st);
+    if (e == hipSuccess) e = gd::pool_alloc(s->device, &d[2], out_bytes, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d[0], o_tmin, n * 16, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d[1], d_tmax, n * 16, hipMemcpyHostToDevice, st);
     int rc = GIGL_OK;
     if (e == hipSuccess)
-        rc = any ? gigl_trace_any_device(s, d[0], d[1], n, (uint64_t*)d[2], nullptr)
-                 : gigl_trace_closest_device(s, d[0], d[1], n, (gigl_hit*)d[2], nullptr);
-    if (e == hipSuccess && rc == GIGL_OK) e = hipMemcpyAsync(out, d[2], out_bytes, hipMemcpyDeviceToHost, nullptr);
-    const hipError_t se = hipStreamSynchronize(nullptr);   // also on failure: nothing may still use the buffers
+        rc = any ? gigl_trace_any_device(s, d[0], d[1], n, (uint64_t*)d[2], st)
+                 : gigl_trace_closest_device(s, d[0], d[1], n, (gigl_hit*)d[2], st);
+    if (e == hipSuccess && rc == GIGL_OK) e = hipMemcpyAsync(out, d[2], out_bytes, hipMemcpyDeviceToHost, st);
+    const hipError_t se = hipStreamSynchronize(st);   // also on failure: nothing may still use the buffers
     release();
     if (rc != GIGL_OK) return rc;
     if (e == hipSuccess) e = se;

@@ -30,7 +30,9 @@ SYMBOLS = [
     "gigl_depth_buffer_device", "gigl_combine_device", "gigl_debug_check_layout", "gigl_scene_layout",
     "gigl_trace_closest_noalloc_device", "gigl_multi_create", "gigl_multi_destroy", "gigl_multi_device_count",
     "gigl_multi_trace_closest_device", "gigl_multi_trace_closest", "gigl_shadow_batch_fused_device",
-    "gigl_debug_launch_info", "gigl_photon_trace_batch",
+    "gigl_debug_launch_info", "gigl_photon_trace_batch", "gigl_multi_trace_closest_device_async",
+    "gigl_multi_trace_any_device", "gigl_multi_trace_any_device_async", "gigl_multi_trace_any",
+    "gigl_scene_export_device_blob", "gigl_scene_create_from_device_blob", "gigl_trim_pool", "gigl_debug_pool_allocs",
 ]
 
 
@@ -53,6 +55,14 @@ class TreeStats(C.Structure):
                 ("max_depth", C.c_int32), ("actual_depth", C.c_int32), ("avg_prims_per_leaf", C.c_float),
                 ("build_ms", C.c_float), ("degenerate_split_guard_hit", C.c_uint32),
                 ("device_bytes", C.c_uint64)]
+
+
+class SceneBlob(C.Structure):
+    """gigl_scene_blob (include/gigl_rt.h): the header of a flattened scene as it lies on its device."""
+    _fields_ = [("magic", C.c_uint32), ("version", C.c_uint32), ("nb_nodes", C.c_uint64), ("nb_leaf_ids", C.c_uint64),
+                ("nb_tris", C.c_uint64), ("layout", C.c_uint32), ("triples", C.c_uint32), ("blocks_off8", C.c_uint32),
+                ("n_tris", C.c_uint32), ("root", C.c_uint32 * 2), ("root_rec", C.c_uint32 * 4), ("box", C.c_float * 6),
+                ("stats", TreeStats)]
 
 
 def lib():
@@ -87,8 +97,16 @@ def lib():
         L.gigl_multi_create.argtypes = [vp, vp, i, vp]
         L.gigl_multi_destroy.argtypes = [vp]
         L.gigl_multi_device_count.argtypes = [vp, vp]
-        L.gigl_multi_trace_closest_device.argtypes = [vp, vp, vp, u64, vp]
+        L.gigl_multi_trace_closest_device.argtypes = [vp, vp, vp, u64, vp, vp]
+        L.gigl_multi_trace_closest_device_async.argtypes = [vp, vp, vp, u64, vp, vp]
+        L.gigl_multi_trace_any_device.argtypes = [vp, vp, vp, u64, vp, vp]
+        L.gigl_multi_trace_any_device_async.argtypes = [vp, vp, vp, u64, vp, vp]
         L.gigl_multi_trace_closest.argtypes = [vp, vp, vp, u64, vp]
+        L.gigl_multi_trace_any.argtypes = [vp, vp, vp, u64, vp]
+        L.gigl_trim_pool.argtypes = [i]
+        L.gigl_debug_pool_allocs.argtypes = [vp]
+        L.gigl_scene_export_device_blob.argtypes = [vp, vp, vp]
+        L.gigl_scene_create_from_device_blob.argtypes = [vp, vp, vp, vp, i, vp, vp]
         L.gigl_trace_any_device.argtypes = [vp, vp, vp, u64, vp, vp]
         L.gigl_trace_any.argtypes = [vp, vp, vp, u64, vp]
         L.gigl_trace_one.argtypes = [vp, vp, vp, f, f, i, vp, vp, vp, vp]
@@ -137,6 +155,16 @@ def _f32(a):
 def device_count():
     n = C.c_int(0)
     _check(lib().gigl_device_count(C.byref(n)))
+    return n.value
+
+
+def trim_pool(device=0):
+    _check(lib().gigl_trim_pool(device))
+
+
+def debug_pool_allocs():
+    n = C.c_uint64(0)
+    _check(lib().gigl_debug_pool_allocs(C.byref(n)))
     return n.value
 
 
@@ -214,6 +242,24 @@ class Scene:
         self.h = h
         self.device = device
         self.n_tris = len(tris)
+
+    @classmethod
+    def from_device_blob(cls, desc, nodes_ptr, leaf_ids_ptr, tris_ptr, device=0, stream=0):
+        """A scene adopted from the flattened arrays of another one (gigl_scene_create_from_device_blob): no
+        build; the arrays are copied, the caller may free them afterwards."""
+        h = C.c_void_p()
+        _check(lib().gigl_scene_create_from_device_blob(C.byref(desc), nodes_ptr, leaf_ids_ptr or None, tris_ptr, device,
+                                                        stream, C.byref(h)))
+        self = cls.__new__(cls)
+        self.h, self.device, self.n_tris = h, device, int(desc.n_tris)
+        return self
+
+    def export_device_blob(self):
+        """(header, [nodes_ptr, leaf_ids_ptr, tris_ptr]): gigl_scene_export_device_blob.  The arrays stay the scene's."""
+        desc = SceneBlob()
+        ptrs = (C.c_void_p * 3)()
+        _check(lib().gigl_scene_export_device_blob(self.h, C.byref(desc), ptrs))
+        return desc, [p or 0 for p in ptrs]
 
     def close(self):
         if getattr(self, "h", None):
@@ -389,8 +435,20 @@ class MultiDeviceScene:
         _check(lib().gigl_multi_trace_closest(self.h, _p(ro), _p(rd), len(ro), _p(hits)))
         return hits
 
-    def trace_closest_device(self, o_ptr, d_ptr, n, hits_ptr):
-        _check(lib().gigl_multi_trace_closest_device(self.h, o_ptr, d_ptr, n, hits_ptr))
+    def trace_any(self, o_tmin, d_tmax):
+        ro, rd = _f32(o_tmin).reshape(-1, 4), _f32(d_tmax).reshape(-1, 4)
+        bits = np.zeros((len(ro) + 63) // 64, np.uint64)
+        _check(lib().gigl_multi_trace_any(self.h, _p(ro), _p(rd), len(ro), _p(bits)))
+        return unpack_bits(bits, len(ro))
+
+    def trace_closest_device(self, o_ptr, d_ptr, n, hits_ptr, stream=0, wait=True):
+        """Ordered behind `stream` (a stream of devices[0]) and `stream` behind it; wait=False returns once enqueued."""
+        f = lib().gigl_multi_trace_closest_device if wait else lib().gigl_multi_trace_closest_device_async
+        _check(f(self.h, o_ptr, d_ptr, n, hits_ptr, stream))
+
+    def trace_any_device(self, o_ptr, d_ptr, n, bits_ptr, stream=0, wait=True):
+        f = lib().gigl_multi_trace_any_device if wait else lib().gigl_multi_trace_any_device_async
+        _check(f(self.h, o_ptr, d_ptr, n, bits_ptr, stream))
 
 
 class FogVolume:

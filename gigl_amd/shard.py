@@ -145,3 +145,71 @@ class ShardedTracer:
         for r, (lo, hi) in enumerate(self.ranges):
             out[lo:hi] = self.gathered[r][: hi - lo]
         return out
+
+
+class _DeviceBytes:
+    """A device address range as an object torch.as_tensor can view without copying."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def replicate_scene(torch, dist, rt, scene, rank, device, backend="nccl", src=0, adopt_on_src=False):
+    """The flattened scene of rank `src` on every rank, without rebuilding it ("uploaded to GPU 0,
+    then ncclBroadcast"): the header and the three device arrays are broadcast and the other ranks adopt them
+    (gigl_scene_create_from_device_blob).  `scene` is rt.Scene on rank src and None elsewhere; returns
+    (scene, info).  With the nccl backend the arrays go device to device (rank src broadcasts straight out of the
+    scene's own memory); with gloo (CPU rehearsal of the rank logic) through host memory.  adopt_on_src: rank src
+    also adopts a copy from the arrays it broadcast (info["adopted_on_src"]; how a one-rank group tests the path)."""
+    import ctypes
+    import time
+    device = torch.device(device)
+    direct = backend == "nccl"
+    t0 = time.time()
+    nhdr = ctypes.sizeof(rt.SceneBlob)
+    ptrs = [0, 0, 0]
+    if rank == src:
+        desc, ptrs = scene.export_device_blob()
+        hdr = torch.frombuffer(bytearray(bytes(desc)), dtype=torch.uint8).clone()
+    else:
+        hdr = torch.zeros(nhdr, dtype=torch.uint8)
+    if direct:
+        hdr = hdr.to(device)
+    dist.broadcast(hdr, src)
+    desc = rt.SceneBlob.from_buffer_copy(hdr.cpu().numpy().tobytes())
+    arrays = []
+    for k, nb in enumerate((desc.nb_nodes, desc.nb_leaf_ids, desc.nb_tris)):
+        if nb == 0:
+            arrays.append(None)
+            continue
+        if rank == src:
+            t = torch.as_tensor(_DeviceBytes(ptrs[k], nb), device=device)
+        else:
+            t = torch.empty(int(nb), dtype=torch.uint8, device=device)
+        if direct:
+            dist.broadcast(t, src)
+        else:
+            c = t.cpu()
+            dist.broadcast(c, src)
+            if rank != src:
+                t.copy_(c)
+        arrays.append(t)
+    if rank != src:
+        torch.cuda.synchronize(device)
+        ptr = lambda t: 0 if t is None else t.data_ptr()
+        scene = rt.Scene.from_device_blob(desc, ptr(arrays[0]), ptr(arrays[1]), ptr(arrays[2]), device=device.index,
+                                          stream=torch.cuda.current_stream(device).cuda_stream)
+    else:
+        torch.cuda.synchronize(device)
+    adopted = None
+    if rank == src and adopt_on_src:
+        ptr = lambda t: 0 if t is None else t.data_ptr()
+        adopted = rt.Scene.from_device_blob(desc, ptr(arrays[0]), ptr(arrays[1]), ptr(arrays[2]), device=device.index,
+                                            stream=torch.cuda.current_stream(device).cuda_stream)
+    del arrays
+    info = {"how": "rank %d builds, header + 3 device arrays broadcast over %s, other ranks adopt them (no rebuild)" % (src, backend),
+            "bytes": int(desc.nb_nodes + desc.nb_leaf_ids + desc.nb_tris), "seconds": round(time.time() - t0, 3)}
+    if adopted is not None:
+        info["adopted_on_src"] = adopted
+    return scene, info

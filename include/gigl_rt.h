@@ -114,24 +114,68 @@ int gigl_trace_any(const gigl_scene* s, const float* o_tmin, const float* d_tmax
                    uint64_t* occluded_bits);
 /* Several devices of one node behind one call: the scene's flattened tree and
  * triangle records are replicated on every device of the list (device to device, over xGMI between
- * two GPUs), a batch is split into contiguous ray ranges whose sizes differ by at most one, each
- * device traces its range (one host thread and one stream per device) and the 16-byte hit records
- * are gathered by direct peer copies, one point-to-point transfer per device: no ring, no reduction.
+ * two GPUs), a batch is split into contiguous ray ranges whose sizes differ by at most one ray
+ * (any-hit batches: by at most one 64-ray word, so that every range owns whole words of the output),
+ * each device traces its range on a stream of its own and the results are gathered by direct peer
+ * copies, one point-to-point transfer per device: no ring, no reduction.
  * Extends Scene::trace over a batch (Source/Common/Scene.cpp:234-243); the reference is a single
  * CPU process and has nothing of the kind.  devices[0] must be the scene's own device (its replica
  * is the scene itself, which must outlive the handle); a device may appear more than once.
- * gigl_multi_trace_closest_device: o_tmin, d_tmax and hits are device pointers on devices[0];
- * gigl_multi_trace_closest: host pointers (each device fetches and returns its own range).  Both are
- * synchronous and return records identical to gigl_trace_closest_device on the whole batch.  One
- * batch at a time per handle. */
+ *
+ * *_device: o_tmin, d_tmax and the output are device pointers on devices[0]; `stream` is a stream of
+ * devices[0] (NULL = its default stream).  The batch is ordered behind everything `stream` holds when
+ * the call is made (rays still being produced on it, a pending fill of the output) and `stream` is
+ * ordered behind the batch: the replicas' own streams wait for an event recorded on `stream`, and
+ * `stream` waits for theirs.  gigl_multi_trace_closest_device / _any_device return when the results
+ * are in place (they synchronise `stream`); the *_async forms return as soon as the work is enqueued,
+ * like the single-device *_device calls.  A handle keeps two sets of replica streams and staging
+ * buffers and alternates between them, so two batches issued on two caller streams overlap.
+ * gigl_multi_trace_closest / _any: host pointers; each device fetches and returns its own range
+ * through gigl_trace_closest / gigl_trace_any on a persistent worker thread of the handle; synchronous.
+ * Results are identical to the single-device calls on the whole batch.  Calls may be issued
+ * concurrently on one handle. */
 typedef struct gigl_multi gigl_multi;
 int gigl_multi_create(const gigl_scene* s, const int* devices, int n_devices, gigl_multi** out);
 int gigl_multi_destroy(gigl_multi* m);
 int gigl_multi_device_count(const gigl_multi* m, int* count);
 int gigl_multi_trace_closest_device(gigl_multi* m, const void* o_tmin, const void* d_tmax, uint64_t n,
-                                    gigl_hit* hits);
+                                    gigl_hit* hits, void* stream);
+int gigl_multi_trace_closest_device_async(gigl_multi* m, const void* o_tmin, const void* d_tmax, uint64_t n,
+                                          gigl_hit* hits, void* stream);
+int gigl_multi_trace_any_device(gigl_multi* m, const void* o_tmin, const void* d_tmax, uint64_t n,
+                                uint64_t* occluded_bits, void* stream);
+int gigl_multi_trace_any_device_async(gigl_multi* m, const void* o_tmin, const void* d_tmax, uint64_t n,
+                                      uint64_t* occluded_bits, void* stream);
 int gigl_multi_trace_closest(gigl_multi* m, const float* o_tmin, const float* d_tmax, uint64_t n,
                              gigl_hit* hits);
+int gigl_multi_trace_any(gigl_multi* m, const float* o_tmin, const float* d_tmax, uint64_t n,
+                         uint64_t* occluded_bits);
+
+/* The flattened scene as it lies on its device, for replication WITHOUT a rebuild: one process per GPU
+ * ("uploaded to GPU 0, then ncclBroadcast").  Rank 0 builds the tree
+ * (gigl_scene_create), exports the header and the device addresses of its three arrays, the caller
+ * moves header and arrays with whatever it has (ncclBroadcast / torch.distributed.broadcast, peer
+ * copies, a file) and every other rank adopts them.  On ranks > 0 this replaces the whole of
+ * rt::KdTree<Triangle>::KdTree (Source/RT/KdTree.hpp:87-132) and the flattening.
+ * gigl_scene_export_device_blob: fills *desc; ptrs_out[0..2] = device addresses of the node / record
+ * array (desc->nb_nodes bytes), the separate leaf id array (nb_leaf_ids bytes, NULL when 0) and the
+ * triangle table with the leaf blocks (nb_tris bytes).  They stay owned by the scene.
+ * gigl_scene_create_from_device_blob: nodes, leaf_ids, tris are device pointers readable from `device`
+ * (on it, or on a peer) holding desc's byte counts; they are COPIED (on `stream`, which is synchronised
+ * before the call returns), so the caller may free them.  The new scene traces exactly as the source
+ * does; it has no host tree (gigl_scene_export_tree and gigl_debug_check_layout fail with GIGL_ERR_INVALID). */
+#define GIGL_BLOB_MAGIC 0x42474947u   /* "GIGB" */
+typedef struct gigl_scene_blob {
+    uint32_t magic, version;                   /* GIGL_BLOB_MAGIC, 1 */
+    uint64_t nb_nodes, nb_leaf_ids, nb_tris;   /* bytes of the three device arrays */
+    uint32_t layout, triples, blocks_off8, n_tris;
+    uint32_t root[2], root_rec[4];
+    float    box[6];                           /* tree box: min xyz, max xyz */
+    gigl_tree_stats stats;
+} gigl_scene_blob;
+int gigl_scene_export_device_blob(const gigl_scene* s, gigl_scene_blob* desc, void* ptrs_out[3]);
+int gigl_scene_create_from_device_blob(const gigl_scene_blob* desc, const void* nodes, const void* leaf_ids,
+                                       const void* tris, int device, void* stream, gigl_scene** out);
 
 /* gigl_trace_closest_device for callers that cannot allocate (code under HIP graph capture, tight
  * serving loops, harnesses that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE.  Same inputs,
@@ -331,6 +375,14 @@ int gigl_debug_last_stats(uint64_t out[12]);
  * CU as the occupancy query reports them (= waves per SIMD: 4 waves per workgroup over 4 SIMDs), and
  * the CU count the persistent grid is sized with.  Diagnostic; bench.py reports it. */
 int gigl_debug_launch_info(const gigl_scene* s, int* blocks_per_cu, int* n_cus);
+
+/* Launch workspaces and staging buffers come from a stream-ordered pool the library owns per device, which keeps
+ * the largest blocks a process ever asked for between calls.  The pool's idle memory goes back to the device when
+ * the last scene on that device is destroyed, or when this is called.  No counterpart in the reference. */
+int gigl_trim_pool(int device);
+/* Number of stream-ordered allocations the library has made so far in this process (diagnostic; the test of
+ * gigl_trace_closest_noalloc_device asserts that a call leaves it unchanged). */
+int gigl_debug_pool_allocs(uint64_t* count);
 
 /* Tuning knobs (process-wide; read at each launch).  Names and meaning in DESIGN.md. */
 int gigl_set_option(const char* name, int value);

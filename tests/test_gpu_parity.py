@@ -499,29 +499,102 @@ def test_shadow_batch_fused_cornell(gpu_cornell, oracle_cornell, cornell_cam, de
 
 @pytest.mark.parametrize("devices", [[0], [0, 0, 0]])
 def test_multi_device_entry_points(s16, devices):
-    """gigl_multi_*: the scene replicated over a device list, contiguous ray ranges, hit records gathered
+    """gigl_multi_*: the scene replicated over a device list, contiguous ray ranges, results gathered
     to devices[0] (peer copies) or to the host.  A one-device list is the plain call; a list that
-    repeats device 0 runs the replication, scatter and gather paths on a one-GPU box.  Records equal
-    gigl_trace_closest_device's on the whole batch, bit for bit."""
+    repeats device 0 runs the replication, scatter and gather paths on a one-GPU box.  Records and
+    occlusion bits equal the single-device calls' on the whole batch, bit for bit.  The batch is ordered
+    behind the caller's stream: the output is filled, and the rays are produced, on that stream right
+    before the call, without a synchronisation in between."""
     torch = pytest.importorskip("torch")
-    n = 200_003   # ragged over 3 ranges
+    n = 200_003   # ragged over 3 ranges, and not a multiple of 64
     ro, rd = synth.bounce_rays(s16["V"], s16["T"], n, 0x3D1CE5)
     d_o, d_d = torch.from_numpy(ro).cuda(), torch.from_numpy(rd).cuda()
+    sh = torch.cuda.current_stream().cuda_stream
     want = torch.empty((n, 4), dtype=torch.int32, device="cuda:0")
-    s16["gpu"].trace_closest_device(d_o.data_ptr(), d_d.data_ptr(), n, want.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    s16["gpu"].trace_closest_device(d_o.data_ptr(), d_d.data_ptr(), n, want.data_ptr(), sh)
+    want_bits = torch.zeros((n + 63) // 64, dtype=torch.int64, device="cuda:0")
+    s16["gpu"].trace_any_device(d_o.data_ptr(), d_d.data_ptr(), n, want_bits.data_ptr(), sh)
     torch.cuda.synchronize()
     m = rt.MultiDeviceScene(s16["gpu"], devices)
     assert m.device_count() == len(devices)
-    for n_call in (n, 1000, n):   # a smaller batch in between: the staging buffers are reused
-        got = torch.full((n_call, 4), -3, dtype=torch.int32, device="cuda:0")
-        m.trace_closest_device(d_o.data_ptr(), d_d.data_ptr(), n_call, got.data_ptr())
+    side = torch.cuda.Stream()
+    for n_call in (n, 1000, n, 64, 65):   # smaller batches in between: the staging buffers are reused
+        for stream in (torch.cuda.current_stream(), side):
+            with torch.cuda.stream(stream):
+                # rays produced and outputs filled on the caller's stream, then the call, no synchronisation
+                c_o, c_d = d_o[:n_call].clone(), d_d[:n_call].clone()
+                got = torch.full((n_call, 4), -3, dtype=torch.int32, device="cuda:0")
+                m.trace_closest_device(c_o.data_ptr(), c_d.data_ptr(), n_call, got.data_ptr(), stream.cuda_stream)
+                assert torch.equal(got, want[:n_call])
+                bits = torch.full(((n_call + 63) // 64,), -1, dtype=torch.int64, device="cuda:0")
+                m.trace_any_device(c_o.data_ptr(), c_d.data_ptr(), n_call, bits.data_ptr(), stream.cuda_stream)
+                g = rt.unpack_bits(bits.cpu().numpy().view(np.uint64), n_call)
+                assert np.array_equal(g, rt.unpack_bits(want_bits.cpu().numpy().view(np.uint64), n)[:n_call])
+    # the asynchronous forms: two batches on two caller streams through the handle's two slots, results read
+    # after the streams (not the device) have been waited for
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = []
+    for i in range(6):
+        st = streams[i % 2]
+        with torch.cuda.stream(st):
+            n_call = n - 7 * i
+            got = torch.full((n_call, 4), -3, dtype=torch.int32, device="cuda:0")
+            bits = torch.zeros((n_call + 63) // 64, dtype=torch.int64, device="cuda:0")
+            m.trace_closest_device(d_o.data_ptr(), d_d.data_ptr(), n_call, got.data_ptr(), st.cuda_stream, wait=False)
+            m.trace_any_device(d_o.data_ptr(), d_d.data_ptr(), n_call, bits.data_ptr(), st.cuda_stream, wait=False)
+            outs.append((n_call, got, bits))
+    for st in streams:
+        st.synchronize()
+    wb = rt.unpack_bits(want_bits.cpu().numpy().view(np.uint64), n)
+    for n_call, got, bits in outs:
         assert torch.equal(got, want[:n_call])
-    host = m.trace(ro, rd)     # host pointers: every device fetches and returns its own range
+        assert np.array_equal(rt.unpack_bits(bits.cpu().numpy().view(np.uint64), n_call), wb[:n_call])
+    host = m.trace(ro, rd)     # host pointers: every device fetches and returns its own range (worker threads)
     assert np.array_equal(host.view(np.uint32).reshape(-1, 4), want.cpu().numpy().view(np.uint32))
+    assert np.array_equal(m.trace_any(ro, rd), wb)
+    assert np.array_equal(m.trace_any(ro[:70], rd[:70]), wb[:70])
     assert len(m.trace(ro[:0], rd[:0])) == 0
     m.close()
     with pytest.raises(rt.GiglError):
         rt.MultiDeviceScene(s16["gpu"], [1_000])   # devices[0] must be the scene's device
+
+
+def test_scene_adopted_from_a_device_blob(s16):
+    """gigl_scene_export_device_blob / gigl_scene_create_from_device_blob: a second scene made from the header
+    and copies of the three device arrays of the first (what a rank does with a broadcast tree) traces bit-equal
+    to it, closest-hit and any-hit, survives the source arrays being freed, and has no host tree."""
+    torch = pytest.importorskip("torch")
+    from gigl_amd import shard
+    src = s16["gpu"]
+    desc, ptrs = src.export_device_blob()
+    assert desc.magic == 0x42474947 and desc.nb_nodes > 0 and desc.nb_tris >= len(s16["T"]) * 64 and ptrs[0] and ptrs[2]
+    copies = [None if not (p and nb) else torch.as_tensor(shard._DeviceBytes(p, nb), device="cuda:0").clone()
+              for p, nb in zip(ptrs, (desc.nb_nodes, desc.nb_leaf_ids, desc.nb_tris))]
+    torch.cuda.synchronize()
+    ptr = lambda t: 0 if t is None else t.data_ptr()
+    rep = rt.Scene.from_device_blob(desc, ptr(copies[0]), ptr(copies[1]), ptr(copies[2]), device=0)
+    for c in copies:
+        if c is not None:
+            c.fill_(0xAB)   # the library copied them
+    del copies
+    torch.cuda.synchronize()
+    n = 100_000
+    ro, rd = synth.bounce_rays(s16["V"], s16["T"], n, 0xB10B)
+    assert np.array_equal(rep.trace(ro, rd).view(np.uint32), src.trace(ro, rd).view(np.uint32))
+    assert np.array_equal(rep.trace(ro, rd, is_vis_ray=True), src.trace(ro, rd, is_vis_ray=True))
+    assert rep.layout() == src.layout() and np.array_equal(rep.bbox(), src.bbox())
+    st, ss = rep.stats(), src.stats()
+    assert (st.n_nodes, st.actual_depth, st.device_bytes) == (ss.n_nodes, ss.actual_depth, ss.device_bytes)
+    hit, rec, nrm = rep.trace_one(ro[5, :3], rd[5, :3])
+    hit2, rec2, nrm2 = src.trace_one(ro[5, :3], rd[5, :3])
+    assert hit == hit2 and rec == rec2 and np.array_equal(nrm, nrm2)
+    with pytest.raises(rt.GiglError):
+        rep.export_tree()   # no host tree
+    bad = rt.SceneBlob.from_buffer_copy(bytes(desc))
+    bad.magic = 1
+    with pytest.raises(rt.GiglError):
+        rt.Scene.from_device_blob(bad, ptrs[0], ptrs[1], ptrs[2], device=0)
+    rep.close()
 
 
 @pytest.mark.parametrize("res", [(96, 64), (1024, 1024)])

@@ -61,6 +61,22 @@ for pipeline in (False, True):
         st2.drain()
         torch.cuda.synchronize()
         assert np.array_equal(st2.result().cpu().numpy(), want[i]), (pipeline, i)
+# the tree replication of bench.py at N > 1: header and device arrays through RCCL broadcasts straight out of the
+# scene's memory, then adopted without a rebuild; the adopted scene traces bit-equal to the source
+same, info = shard.replicate_scene(torch, dist, rt, scene, 0, torch.device("cuda", 0), backend="nccl", adopt_on_src=True)
+assert same is scene and info["bytes"] == scene.stats().device_bytes
+rep = info["adopted_on_src"]
+o, d = dev[0]
+h = torch.empty((n, 4), dtype=torch.int32, device="cuda:0")
+rep.trace_closest_device(o.data_ptr(), d.data_ptr(), n, h.data_ptr(), torch.cuda.current_stream().cuda_stream)
+torch.cuda.synchronize()
+assert np.array_equal(h.cpu().numpy(), want[0]), "adopted scene"
+try:
+    rep.export_tree()
+    raise AssertionError("an adopted scene has no host tree")
+except rt.GiglError:
+    pass
+rep.close()
 dist.barrier()
 dist.destroy_process_group()
 scene.close()

@@ -132,3 +132,24 @@ def test_multi_device_host_pointer_ranges_are_pipelined(s64):
         got = m.trace(s64["ro"], s64["rd"])
         assert np.array_equal(got.view(np.uint32).reshape(-1, 4), want.view(np.uint32))
     m.close()
+
+
+def test_pool_is_trimmed_on_request_and_with_the_last_scene(cornell):
+    """The library's stream-ordered pool keeps its largest blocks between calls; gigl_trim_pool,
+    and the destruction of the last scene on a device, give the idle memory back."""
+    torch = pytest.importorskip("torch")
+    torch.cuda.synchronize()
+    V, T = synth.tessellate(cornell["verts"], cornell["tris"], 8)
+    g = rt.Scene(V, T, device=0, **S.KD_PARAMS)
+    n = 1 << 20
+    ro, rd = synth.bounce_rays(V, T, n, 0x7121)
+    want = g.trace(ro, rd)            # host pointers: 48 MB of staging from the pool
+    torch.cuda.synchronize()
+    held = torch.cuda.mem_get_info(0)[0]
+    rt.trim_pool(0)
+    after = torch.cuda.mem_get_info(0)[0]
+    assert after >= held + (40 << 20), (held, after)    # the staging went back
+    assert np.array_equal(g.trace(ro, rd).view(np.uint32), want.view(np.uint32))   # and the pool still serves
+    with pytest.raises(rt.GiglError):
+        rt.trim_pool(1000)
+    g.close()

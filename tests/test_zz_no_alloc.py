@@ -49,6 +49,32 @@ def test_noalloc_matches_allocating_entry_point(cornell):
     gc.close()
 
 
+def test_noalloc_call_allocates_nothing(cornell):
+    """What the name promises: a warm call makes no stream-ordered allocation from the library's pool (its counter
+    of pool allocations stays put, where the ordinary entry point moves it) and the device's free memory is what it
+    was before the call."""
+    torch = pytest.importorskip("torch")
+    V, T = synth.tessellate(cornell["verts"], cornell["tris"], 16)
+    g = rt.Scene(V, T, device=0, **S.KD_PARAMS)
+    n = 50_000
+    ro, rd = synth.bounce_rays(V, T, n, 0xA110C04)
+    d_o, d_d = torch.from_numpy(ro).cuda(), torch.from_numpy(rd).cuda()
+    out = torch.zeros((n, 4), dtype=torch.int32, device="cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    g.trace_closest_noalloc_device(d_o.data_ptr(), d_d.data_ptr(), n, out.data_ptr(), st)   # warm: module loaded
+    torch.cuda.synchronize()
+    allocs, free0 = rt.debug_pool_allocs(), torch.cuda.mem_get_info(0)[0]
+    for _ in range(3):
+        g.trace_closest_noalloc_device(d_o.data_ptr(), d_d.data_ptr(), n, out.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert rt.debug_pool_allocs() == allocs, "the no-allocation entry point went through the pool"
+    assert torch.cuda.mem_get_info(0)[0] == free0
+    g.trace_closest_device(d_o.data_ptr(), d_d.data_ptr(), n, out.data_ptr(), st)   # the counter does count
+    torch.cuda.synchronize()
+    assert rt.debug_pool_allocs() > allocs
+    g.close()
+
+
 def test_noalloc_under_graph_capture(cornell):
     """The callers the entry point is for: captured once in a HIP graph, replayed several times, and once more
     after new rays were written into the same buffers.  Every replay equals gigl_trace_closest_device."""
