@@ -305,6 +305,9 @@ struct gigl_scene {
     // gigl_photon_trace_batch: a workspace kept between calls (grown on demand), used on one_stream under one_mu
     void* photon_ws = nullptr;
     size_t photon_ws_bytes = 0;
+    bool photon_ws_fresh = false;        // just allocated: its traversal work counter has not been cleared yet
+    void* photon_h = nullptr;            // small sets (one launch): page-locked, device-mapped staging the kernel writes
+    void* photon_h_dev = nullptr;        // records and totals into (host address / the same memory as the device sees it)
     std::vector<float> photon_mats;      // the materials last uploaded into photon_ws, and where
     const void* photon_mats_at = nullptr;
 };
@@ -334,6 +337,8 @@ int scene_clone_to_device(const gigl_scene* src, int device, gigl_scene** out);
 int trace_closest_ranges(const gigl_scene* s, const float4* o_tmin, const float4* d_tmax, unsigned n, uint4* hits,
                          float2* ranges, float4* hit_tri, hipStream_t st, void* ws = nullptr, unsigned ws_blocks = 0);
 size_t trace_workspace_bytes(unsigned blocks);
+void scene_trace_params(const gigl_scene* s, TraceParams& P);
+int option_photon_small();
 
 // gigl_rt.hip: stream-ordered allocation from the library's own pool on `device` (release with hipFreeAsync)
 hipError_t pool_alloc(int device, void** p, size_t bytes, hipStream_t st);

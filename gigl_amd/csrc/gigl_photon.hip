@@ -17,7 +17,7 @@
 // float arithmetic of the reference in the reference's order (-ffp-contract=off).
 #include <cstring>
 
-#include "gigl_internal.h"
+#include "gigl_trace_body.h"   // the traversal body: photon_small_kernel walks the tree itself
 
 using namespace gd;
 
@@ -114,12 +114,8 @@ __device__ __forceinline__ void retire(const WalkParams& W, unsigned i, PathStat
     W.d_tmax[i].w = -FLT_MAX;
 }
 
-// PhotonTracer.cpp:84-93: the start of a path
-__global__ void __launch_bounds__(256) photon_start_kernel(const WalkParams W) {
-    const unsigned i = blockIdx.x * 256u + threadIdx.x;
-    if (i == 0u) *W.trace_counter = 0u;
-    if (i < W.n_total_words) W.totals[i] = 0u;
-    if (i >= W.n) return;
+// PhotonTracer.cpp:84-93: the start of path i of the block
+__device__ __forceinline__ void path_start(const WalkParams& W, unsigned i) {
     Draw draw{path_key(W.seed, W.first + i), 0u};
     if (W.src[2] <= kMaxFogHeight) (void)draw();   // :86 — the draw is made, its result never reaches the path (:88-92)
     const float u1 = draw(), u0 = draw();          // :90, arguments evaluated right to left
@@ -133,16 +129,20 @@ __global__ void __launch_bounds__(256) photon_start_kernel(const WalkParams W) {
     W.state[i] = st;
     store_ray(W, i, f3(W.src[0], W.src[1], W.src[2]), dir);
 }
+__global__ void __launch_bounds__(256) photon_start_kernel(const WalkParams W) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i == 0u) *W.trace_counter = 0u;
+    if (i < W.n_total_words) W.totals[i] = 0u;
+    if (i >= W.n) return;
+    path_start(W, i);
+}
 
 __device__ __forceinline__ float sample_density(const FogParams& F, F3 p) {   // DensityField.cpp:177-202, BBox.cpp:53-55
     return fog_filter(F, (p.x - F.mnx) / (F.mxx - F.mnx), (p.y - F.mny) / (F.mxy - F.mny), (p.z - F.mnz) / (F.mxz - F.mnz));
 }
 
-// PhotonTracer.cpp:95-178: what happens to a path after scene.trace(ray), one lane per path
-__global__ void __launch_bounds__(256) photon_bounce_kernel(const WalkParams W, int last_bounce) {
-    const unsigned i = blockIdx.x * 256u + threadIdx.x;
-    if (i == 0u) *W.trace_counter = 0u;
-    if (i >= W.n) return;
+// PhotonTracer.cpp:95-178: what happens to path i of the block after scene.trace(ray), one lane per path
+__device__ __forceinline__ void path_bounce(const WalkParams& W, unsigned i, int last_bounce) {
     PathState st = W.state[i];
     if (!st.alive) return;
     Draw draw{path_key(W.seed, W.first + i), st.k};
@@ -277,6 +277,12 @@ __global__ void __launch_bounds__(256) photon_bounce_kernel(const WalkParams W, 
     }
     W.state[i] = st;
 }
+__global__ void __launch_bounds__(256) photon_bounce_kernel(const WalkParams W, int last_bounce) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i == 0u) *W.trace_counter = 0u;
+    if (i >= W.n) return;
+    path_bounce(W, i, last_bounce);
+}
 
 // ---- keeping the first max_vpl_count records in path order --------------------------------------
 // Running totals over the blocks of paths walked so far.
@@ -368,6 +374,108 @@ __global__ void __launch_bounds__(256) vpl_normalize_kernel(VplRec* out, unsigne
     for (int k = 4; k < 7; ++k) out[i].w[k] = __float_as_uint(__uint_as_float(out[i].w[k]) * inv);
 }
 
+
+// ---- a whole small set in one launch ---------------------------------------------------------------
+// The batched route above is a chain of a dozen dependent launches and a read-back per block of paths:
+// 0.21 ms for the reference's own 150-VPL set, of which the walk itself is a quarter.  For sets of up to
+// kSmallMaxVpls one workgroup does everything: its 1,024 lanes are 1,024 paths; per bounce the workgroup
+// walks the tree itself (trace_body, the same traversal code as every other query, fed from the block's
+// own ray arrays through the usual work counter, which its last wave out leaves at zero), then every lane
+// advances its path; the ordered gather is a workgroup scan; further blocks of 1,024 paths follow inside
+// the kernel until record number max_vpl_count exists or 100 * max_vpl_count paths are used up
+// (PhotonTracer.cpp:180); the kept records, scaled by 1 / n_paths (LightArray.hpp:46-66), and the totals
+// go straight into page-locked host memory.  One launch, one synchronisation, no copy.  Same arithmetic,
+// same order of records: byte-identical to the batched route.
+constexpr int kSmallBlock = 1024;
+constexpr unsigned kSmallMaxVpls = 1024;
+
+// phases of one workgroup exchange their data through global memory (L2): the barrier orders them, the fence
+// drops what the CU's vector cache may still hold of the lines another wave has rewritten
+__device__ __forceinline__ void phase_sync() {
+    __threadfence();
+    __syncthreads();
+    __threadfence();
+}
+
+template <bool TRIPLES>
+__global__ void __launch_bounds__(kSmallBlock) photon_small_kernel(WalkParams W, const TraceParams P, unsigned max_vpl,
+                                                                   unsigned path_limit, VplRec* d_out, VplRec* h_out,
+                                                                   Acc* h_acc) {
+    __shared__ unsigned long long s_wave_tot[kSmallBlock / 64];
+    __shared__ Acc s_acc;
+    const unsigned i = threadIdx.x, lane = i & 63u, wave = i >> 6;
+    if (i == 0u) {
+        s_acc = Acc{};
+        *W.error = 0u;
+    }
+    __syncthreads();
+    unsigned first = 0u;
+    while (first < path_limit) {
+        const unsigned nb = path_limit - first < (unsigned)kSmallBlock ? path_limit - first : (unsigned)kSmallBlock;
+        W.first = first;
+        W.n = nb;
+        if (i < nb) path_start(W, i);
+        for (int b = 1; b <= kGiBounces; ++b) {
+            phase_sync();
+            TraceParams Q = P;
+            Q.n = nb;
+            trace_body<TRIPLES, false, 0, 8, kSmallBlock>(Q);
+            phase_sync();
+            if (i < nb) path_bounce(W, i, b == kGiBounces ? 1 : 0);
+        }
+        phase_sync();
+        // the ordered gather (vpl_gather_kernel's, as one workgroup scan)
+        const unsigned long long mine = i < nb ? path_counts(W.state[i]) : 0ull;
+        unsigned long long v = mine;
+#pragma unroll
+        for (unsigned off = 1; off < 64u; off <<= 1) {
+            const unsigned long long t = __shfl_up(v, off);
+            if (lane >= off) v += t;
+        }
+        if (lane == 63u) s_wave_tot[wave] = v;
+        __syncthreads();
+        unsigned long long before = 0ull, total = 0ull;
+        for (unsigned w = 0; w < (unsigned)kSmallBlock / 64u; ++w) {
+            const unsigned long long t = s_wave_tot[w];
+            if (w < wave) before += t;
+            total += t;
+        }
+        const unsigned long long excl = before + v - mine;
+        const unsigned base = s_acc.size + (unsigned)(excl & 0xFFFFFFFFull);
+        const unsigned new_id = s_acc.contrib + (unsigned)(excl >> 32);
+        const unsigned cnt = (unsigned)(mine & 0xFFFFFFFFull);
+        __syncthreads();   // everyone has read the totals before they move
+        for (unsigned j = 0; j < cnt; ++j) {
+            const unsigned pos = base + j;
+            if (pos >= max_vpl) break;
+            VplRec r = W.slots[(size_t)i * kGiBounces + j];
+            r.w[11] = new_id;
+            d_out[pos] = r;
+            if (pos + 1u == max_vpl) {   // the serial loop stops inside this path: it is the last one counted
+                s_acc.n_paths = first + i + 1u;
+                s_acc.done = 1u;
+            }
+        }
+        if (i == 0u) {
+            s_acc.size += (unsigned)(total & 0xFFFFFFFFull);
+            s_acc.contrib += (unsigned)(total >> 32);
+            if (*W.error) s_acc.error = 1u;
+        }
+        phase_sync();
+        if (s_acc.done || s_acc.error) break;
+        first += nb;
+    }
+    if (s_acc.done && !s_acc.error) {
+        const float inv = 1.0f / (float)(int)s_acc.n_paths;   // LightArray.hpp:47
+        for (unsigned k = i; k < max_vpl; k += (unsigned)kSmallBlock) {
+            VplRec r = d_out[k];
+            for (int c = 4; c < 7; ++c) r.w[c] = __float_as_uint(__uint_as_float(r.w[c]) * inv);
+            h_out[k] = r;
+        }
+    }
+    if (i == 0u) *h_acc = s_acc;
+}
+
 }  // namespace
 
 extern "C" int gigl_photon_trace_batch(const gigl_scene* s, const gigl_fog* fog, const float* materials, uint32_t n_mat,
@@ -403,7 +511,12 @@ extern "C" int gigl_photon_trace_batch(const gigl_scene* s, const gigl_fog* fog,
     const size_t o_mat = take((size_t)n_mat * 48);
     // the traversal launches' workspace (work counter + stack spill area), so that they neither allocate nor clear
     const unsigned trace_blocks = std::min<unsigned>(n_blocks, (unsigned)s->n_cus * 6u);
-    const size_t o_tws = take(trace_workspace_bytes(trace_blocks));
+    // a small set in one launch (photon_small_kernel): one workgroup of 1,024 lanes, whose traversal spills into
+    // the same workspace (1,024 lanes = 4 of the batched launches' 256-lane workgroups)
+    const int small_opt = option_photon_small();
+    const bool small = (unsigned)max_vpl_count <= kSmallMaxVpls && (small_opt == 1 || (small_opt < 0 && paths_per_batch == 0)) &&
+                       P >= (unsigned)kSmallBlock;
+    const size_t o_tws = take(trace_workspace_bytes(std::max<unsigned>(trace_blocks, kSmallBlock / 256)));
     // the workspace and the stream belong to the scene and are kept between calls (a 150-VPL set is a
     // dozen short launches: allocating per call would cost as much as the walk); calls on one scene serialise
     gigl_scene* ms = const_cast<gigl_scene*>(s);
@@ -414,6 +527,7 @@ extern "C" int gigl_photon_trace_batch(const gigl_scene* s, const gigl_fog* fog,
         ms->photon_mats.clear(); ms->photon_mats_at = nullptr;
         HIP_TRY(hipMalloc(&ms->photon_ws, off));
         ms->photon_ws_bytes = off;
+        ms->photon_ws_fresh = true;
     }
     char* const ws = (char*)ms->photon_ws;
     const hipStream_t st = ms->one_stream;
@@ -449,6 +563,46 @@ extern "C" int gigl_photon_trace_batch(const gigl_scene* s, const gigl_fog* fog,
         unsigned long long* sums = (unsigned long long*)(ws + o_sums);
         Acc* d_acc = (Acc*)(ws + o_acc);
         VplRec* d_out = (VplRec*)(ws + o_out);
+        if (small) {
+            constexpr size_t h_bytes = (size_t)kSmallMaxVpls * sizeof(VplRec) + 256;
+            if (!ms->photon_h) {
+                HIP_TRY(hipHostMalloc(&ms->photon_h, h_bytes, hipHostMallocMapped));
+                HIP_TRY(hipHostGetDevicePointer(&ms->photon_h_dev, ms->photon_h, 0));
+            }
+            TraceParams Q = {};
+            scene_trace_params(s, Q);
+            Q.o_tmin = W.o_tmin; Q.d_tmax = W.d_tmax;
+            Q.hits = (uint4*)(ws + o_hits); Q.ranges = (float2*)(ws + o_rng); Q.hit_tri = (float4*)(ws + o_tri);
+            Q.counter = (unsigned*)(ws + o_tws);
+            Q.spill = (uint4*)(ws + o_tws + 256);
+            Q.spill_stride = (unsigned)kSmallBlock;
+            Q.refill_thresh = 24; Q.chunk = 64u; Q.guided = 0u; Q.t_exit = 20;
+            Q.reset_counter = 1u;   // the last wave out of every traversal leaves the counter at zero for the next bounce
+            // the counter words start at zero: the batched route's kernels and every traversal leave them so, and a
+            // fresh workspace is cleared here
+            if (ms->photon_ws_fresh) {
+                HIP_TRY(hipMemsetAsync(ws + o_tws, 0, 256, st));
+                ms->photon_ws_fresh = false;
+            }
+            VplRec* h_out = (VplRec*)ms->photon_h_dev;
+            Acc* h_acc = (Acc*)((char*)ms->photon_h_dev + (size_t)kSmallMaxVpls * sizeof(VplRec));
+            auto kern = s->triples ? photon_small_kernel<true> : photon_small_kernel<false>;
+            hipLaunchKernelGGL(kern, dim3(1), dim3(kSmallBlock), 0, st, W, Q, (unsigned)max_vpl_count, (unsigned)path_limit,
+                               d_out, h_out, h_acc);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(st));
+            std::memcpy(&acc, (char*)ms->photon_h + (size_t)kSmallMaxVpls * sizeof(VplRec), sizeof(Acc));
+            if (acc.error) return fail(GIGL_ERR_INVALID, "a hit triangle names a material beyond n_mat");
+            if (!acc.done) {   // :181-184
+                std::memset(vpls_out, 0, (size_t)max_vpl_count * sizeof(VplRec));
+                if (n_paths_out) *n_paths_out = (uint32_t)path_limit;
+                return GIGL_OK;
+            }
+            std::memcpy(vpls_out, ms->photon_h, (size_t)max_vpl_count * sizeof(VplRec));
+            *n_vpls_out = max_vpl_count;
+            if (n_paths_out) *n_paths_out = acc.n_paths;
+            return GIGL_OK;
+        }
         uint64_t first = 0;
         while (first < path_limit) {
             const unsigned nb = (unsigned)std::min<uint64_t>(P, path_limit - first);

@@ -13,6 +13,16 @@ from oracle import oracle_py as O
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=[0, 1], ids=["batched", "one_launch"])
+def route(request):
+    """Every test runs through both routes of gigl_photon_trace_batch: the chain of batched launches, and (sets of
+    up to 1,024 VPLs) the one-workgroup kernel that walks a whole set in one launch.  Larger sets take the batched
+    route under either setting."""
+    rt.set_option("photon_small", request.param)
+    yield request.param
+    rt.set_option("photon_small", -1)
+
+
 @pytest.fixture(scope="module")
 def setup(cornell, oracle_cornell, density, fog_box):
     gpu = rt.Scene(cornell["verts"], cornell["tris"], device=0, **S.KD_PARAMS)
@@ -109,3 +119,20 @@ def test_vpl_batch_on_a_tessellated_scene(cornell, density, fog_box, leaf_blocks
     finally:
         gfog.close()
         gpu.close()
+
+
+def test_default_route_is_one_launch_for_the_reference_sized_set(setup):
+    """Option photon_small = -1 (the default): a 150-VPL set asked for without a block size goes through the
+    one-launch kernel, a block size keeps the batched route; records are the same, and calls of the two routes
+    may alternate on one scene (they share the workspace and its work counter)."""
+    rt.set_option("photon_small", -1)
+    seen = []
+    for per in (0, 1024, 0, 256, 0):
+        (n, want, want_paths), (g_n, got, got_paths) = _both(setup, 1, S.MAX_N_VPLS, 4242, per)
+        assert g_n == n == S.MAX_N_VPLS and got_paths == want_paths and np.array_equal(got, want)
+        seen.append(got)
+    assert all(np.array_equal(seen[0], g) for g in seen)
+    # several blocks of 1,024 paths inside the one-launch kernel: 1,000 VPLs need about 3,000 paths
+    rt.set_option("photon_small", 1)
+    (n, want, want_paths), (g_n, got, got_paths) = _both(setup, 1, 1000, 9)
+    assert g_n == n == 1000 and got_paths == want_paths > 2048 and np.array_equal(got, want)
