@@ -305,7 +305,8 @@ struct gigl_scene {
     // gigl_photon_trace_batch: a workspace kept between calls (grown on demand), used on one_stream under one_mu
     void* photon_ws = nullptr;
     size_t photon_ws_bytes = 0;
-    bool photon_ws_fresh = false;        // just allocated: its traversal work counter has not been cleared yet
+    unsigned photon_epoch = 0;           // the one-launch route's barrier count
+    const void* photon_small_at = nullptr;   // where in photon_ws the one-launch route's ticket word was last cleared
     void* photon_h = nullptr;            // small sets (one launch): page-locked, device-mapped staging the kernel writes
     void* photon_h_dev = nullptr;        // records and totals into (host address / the same memory as the device sees it)
     std::vector<float> photon_mats;      // the materials last uploaded into photon_ws, and where

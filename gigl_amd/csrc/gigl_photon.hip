@@ -377,103 +377,184 @@ __global__ void __launch_bounds__(256) vpl_normalize_kernel(VplRec* out, unsigne
 
 // ---- a whole small set in one launch ---------------------------------------------------------------
 // The batched route above is a chain of a dozen dependent launches and a read-back per block of paths:
-// 0.21 ms for the reference's own 150-VPL set, of which the walk itself is a quarter.  For sets of up to
-// kSmallMaxVpls one workgroup does everything: its 1,024 lanes are 1,024 paths; per bounce the workgroup
-// walks the tree itself (trace_body, the same traversal code as every other query, fed from the block's
-// own ray arrays through the usual work counter, which its last wave out leaves at zero), then every lane
-// advances its path; the ordered gather is a workgroup scan; further blocks of 1,024 paths follow inside
-// the kernel until record number max_vpl_count exists or 100 * max_vpl_count paths are used up
-// (PhotonTracer.cpp:180); the kept records, scaled by 1 / n_paths (LightArray.hpp:46-66), and the totals
-// go straight into page-locked host memory.  One launch, one synchronisation, no copy.  Same arithmetic,
-// same order of records: byte-identical to the batched route.
-constexpr int kSmallBlock = 1024;
-constexpr unsigned kSmallMaxVpls = 1024;
+// 0.21 ms for the reference's own 150-VPL set.  For blocks of up to kSmallMaxPaths paths one launch does
+// everything: a workgroup is ONE wave that walks 8 to 32 paths on its first lanes (the fewer paths a wave holds,
+// the fewer rounds its divergent loops take, and up to 128 such waves spread over the chip; none of them waits
+// for another during the walk); per bounce the wave walks the tree itself (trace_body, the same traversal code as
+// every other query, fed from the wave's own rays through a work counter of its own), then every lane advances
+// its path.  The ordered gather: the waves publish their record counts and meet at one barrier in global memory;
+// behind it every wave knows where its records go and places them; the last wave to check out scales the set
+// (LightArray::normalizeIntensity, LightArray.hpp:46-66) and writes it and the totals straight into page-locked
+// host memory.  One launch, one synchronisation, no copy.  Same arithmetic, same order of records: byte-identical
+// to the batched route.  What a set costs is then one wave's dependent chain: three tree walks of about 10 us
+// (the walk of the longest of its rays, some 4,000 instructions issued one every 4-5 cycles: walking the scene
+// from a copy in LDS changed nothing) and three path steps of about 5 us.
+constexpr unsigned kSmallMaxPaths = 4096;   // 128 waves: their totals are scanned by one wave, two per lane
+constexpr unsigned kSmallMaxVpls = 1024;    // records the page-locked staging holds
 
-// phases of one workgroup exchange their data through global memory (L2): the barrier orders them, the fence
-// drops what the CU's vector cache may still hold of the lines another wave has rewritten
-__device__ __forceinline__ void phase_sync() {
-    __threadfence();
-    __syncthreads();
-    __threadfence();
+// the phases of a wave exchange their data through global memory: the fence completes the stores before the loads
+// of the next phase are issued
+__device__ __forceinline__ void phase_fence() {
+    // one wave, one CU: workgroup scope is enough (the CU's vector cache is write-through and shared by its waves)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ unsigned long long wave_inclusive_scan(unsigned long long v, unsigned lane) {
+#pragma unroll
+    for (unsigned off = 1; off < 64u; off <<= 1) {
+        const unsigned long long t = __shfl_up(v, off);
+        if (lane >= off) v += t;
+    }
+    return v;
 }
 
-template <bool TRIPLES>
-__global__ void __launch_bounds__(kSmallBlock) photon_small_kernel(WalkParams W, const TraceParams P, unsigned max_vpl,
-                                                                   unsigned path_limit, VplRec* d_out, VplRec* h_out,
-                                                                   Acc* h_acc) {
-    __shared__ unsigned long long s_wave_tot[kSmallBlock / 64];
-    __shared__ Acc s_acc;
-    const unsigned i = threadIdx.x, lane = i & 63u, wave = i >> 6;
-    if (i == 0u) {
-        s_acc = Acc{};
-        *W.error = 0u;
+// Every wave of the launch arrives, then waits until the counter has reached `target` (the counter only grows: the
+// host hands every launch the value it starts from).  Returns true if the wait gave up: a wave never spins for ever.
+__device__ __forceinline__ bool grid_barrier(unsigned* ctr, unsigned target, unsigned lane) {
+    __threadfence();   // what this wave wrote is out before it arrives
+    bool gave_up = false;
+    if (lane == 0u) {
+        atomicAdd(ctr, 1u);
+        unsigned spins = 0u;
+        while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+            if (++spins > (1u << 22)) { gave_up = true; break; }   // seconds: the other waves never came
+            __builtin_amdgcn_s_sleep(1);
+        }
     }
-    __syncthreads();
-    unsigned first = 0u;
-    while (first < path_limit) {
-        const unsigned nb = path_limit - first < (unsigned)kSmallBlock ? path_limit - first : (unsigned)kSmallBlock;
-        W.first = first;
-        W.n = nb;
-        if (i < nb) path_start(W, i);
-        for (int b = 1; b <= kGiBounces; ++b) {
-            phase_sync();
-            TraceParams Q = P;
-            Q.n = nb;
-            trace_body<TRIPLES, false, 0, 8, kSmallBlock>(Q);
-            phase_sync();
-            if (i < nb) path_bounce(W, i, b == kGiBounces ? 1 : 0);
-        }
-        phase_sync();
-        // the ordered gather (vpl_gather_kernel's, as one workgroup scan)
-        const unsigned long long mine = i < nb ? path_counts(W.state[i]) : 0ull;
-        unsigned long long v = mine;
-#pragma unroll
-        for (unsigned off = 1; off < 64u; off <<= 1) {
-            const unsigned long long t = __shfl_up(v, off);
-            if (lane >= off) v += t;
-        }
-        if (lane == 63u) s_wave_tot[wave] = v;
-        __syncthreads();
-        unsigned long long before = 0ull, total = 0ull;
-        for (unsigned w = 0; w < (unsigned)kSmallBlock / 64u; ++w) {
-            const unsigned long long t = s_wave_tot[w];
-            if (w < wave) before += t;
-            total += t;
-        }
-        const unsigned long long excl = before + v - mine;
-        const unsigned base = s_acc.size + (unsigned)(excl & 0xFFFFFFFFull);
-        const unsigned new_id = s_acc.contrib + (unsigned)(excl >> 32);
-        const unsigned cnt = (unsigned)(mine & 0xFFFFFFFFull);
-        __syncthreads();   // everyone has read the totals before they move
+    __builtin_amdgcn_wave_barrier();
+    __threadfence();   // and what the others wrote is seen after it
+    return gave_up;
+}
+
+struct SmallParams {
+    unsigned max_vpl;
+    VplRec* d_out;                   // kept records (device), unscaled
+    VplRec* h_out;                   // page-locked host memory as the device sees it: the finished set
+    Acc* d_acc;                      // running totals over the launches of one call
+    Acc* h_acc;                      // the same, for the host
+    unsigned long long* wg_totals;   // per wave of the launch: (records, contributing paths)
+    unsigned* barrier;               // arrivals at the grid barriers; only grows
+    unsigned epoch;                  // its value when this launch starts
+    unsigned long long* wg_masks;    // per wave: bit 0 and bit 1 of the record count of each of its paths
+    unsigned* counters;              // two words per wave: its traversal work counter
+    unsigned lanes;                  // paths per wave: 8, 16, 32 (or 64)
+};
+
+template <bool TRIPLES>
+__global__ void __launch_bounds__(64) photon_small_kernel(const WalkParams W, const TraceParams P, const SmallParams K) {
+    // a wave walks K.lanes paths (8, 16 or 32; any divisor of 64 works) on its first lanes: fewer paths per wave means fewer rounds of the
+    // divergent loops (tree walk, Woodcock tracking) per wave, and the waves have the whole chip to spread over
+    const unsigned L = K.lanes;
+    const unsigned g = blockIdx.x, lane = threadIdx.x;
+    const unsigned nb = W.n;
+    const bool mine_path = lane < L && g * L + lane < nb;
+    const unsigned i = mine_path ? g * L + lane : 0u;
+    TraceParams Q = P;
+    Q.o_tmin = P.o_tmin + g * L; Q.d_tmax = P.d_tmax + g * L;
+    Q.hits = P.hits + g * L; Q.ranges = P.ranges + g * L; Q.hit_tri = P.hit_tri + 3u * g * L;
+    Q.n = nb - g * L < L ? nb - g * L : L;
+    Q.counter = K.counters + 2u * g;
+    if (mine_path) path_start(W, i);
+    for (int b = 1; b <= kGiBounces; ++b) {
+        if (lane == 0u) Q.counter[0] = 0u;
+        phase_fence();
+        trace_body<TRIPLES, false, 0, 8, 64>(Q);
+        phase_fence();
+        if (mine_path) path_bounce(W, i, b == kGiBounces ? 1 : 0);
+    }
+    // ---- the ordered gather (vpl_gather_kernel's), every wave placing its own records ----
+    // The waves of a launch (at most 128 single-wave workgroups: all resident at once) meet once at a barrier in
+    // global memory, having published how many records each holds, and how many each of its paths holds (two bit
+    // masks per wave).  Behind it every wave knows where its own records go, which path supplies record number
+    // max_vpl — the last path the serial loop counts — and with it 1 / n_paths.
+    const unsigned cnt = mine_path ? W.state[i].n_vpl : 0u;   // this lane's own store; at most kGiBounces = 3
+    const unsigned long long mine = (unsigned long long)cnt | ((unsigned long long)(cnt ? 1u : 0u) << 32);
+    const unsigned long long incl = wave_inclusive_scan(mine, lane);
+    const unsigned long long b0 = __ballot((cnt & 1u) != 0u), b1 = __ballot((cnt & 2u) != 0u);
+    if (lane == 63u) {
+        K.wg_totals[g] = incl;
+        K.wg_masks[2u * g] = b0;
+        K.wg_masks[2u * g + 1u] = b1;
+    }
+    const bool timed_out = grid_barrier(K.barrier, K.epoch + gridDim.x, lane);
+    const unsigned n_w = gridDim.x;
+    const unsigned long long t0 = lane < n_w ? __hip_atomic_load(K.wg_totals + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    const unsigned long long t1 = lane + 64u < n_w ? __hip_atomic_load(K.wg_totals + lane + 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    const unsigned long long i0 = wave_inclusive_scan(t0, lane);
+    const unsigned long long i1 = wave_inclusive_scan(t1, lane) + __shfl(i0, 63);
+    const unsigned long long grand = __shfl(i1, 63);
+    auto incl_of = [&](unsigned w) { return w < 64u ? __shfl(i0, (int)w) : __shfl(i1, (int)(w - 64u)); };   // w wave-uniform
+    const unsigned long long before = g == 0u ? 0ull : incl_of(g - 1u);
+    Acc acc = {};
+    if (W.first != 0u) acc = *K.d_acc;   // the launches before this one; rewritten by wave 0 at the very end
+    // which path supplies record number max_vpl, if any of this launch does
+    const unsigned need = K.max_vpl - acc.size;   // records still missing (> 0: a complete set ends the call)
+    const unsigned long long m0 = __ballot(lane < n_w && (unsigned)(i0 & 0xFFFFFFFFull) >= need);
+    const unsigned long long m1 = __ballot(lane + 64u < n_w && (unsigned)(i1 & 0xFFFFFFFFull) >= need);
+    const bool done = (m0 | m1) != 0ull;
+    float inv = 0.0f;
+    if (done) {
+        const unsigned gd = m0 ? (unsigned)__ffsll((long long)m0) - 1u : 63u + (unsigned)__ffsll((long long)m1);
+        const unsigned need_in = need - (unsigned)((gd == 0u ? 0ull : incl_of(gd - 1u)) & 0xFFFFFFFFull);
+        const unsigned long long d0 = __hip_atomic_load(K.wg_masks + 2u * gd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long d1 = __hip_atomic_load(K.wg_masks + 2u * gd + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long le = lane == 63u ? ~0ull : (1ull << (lane + 1u)) - 1ull;
+        const unsigned pref = (unsigned)__popcll(d0 & le) + 2u * (unsigned)__popcll(d1 & le);
+        const unsigned long long md = __ballot(pref >= need_in);
+        acc.done = 1u;
+        acc.n_paths = W.first + gd * L + (unsigned)__ffsll((long long)md);   // path index + 1 (PhotonTracer.cpp:115, :159, :180)
+        inv = 1.0f / (float)(int)acc.n_paths;   // LightArray.hpp:47
+    }
+    {
+        const unsigned long long excl = before + incl - mine;
+        const unsigned base = acc.size + (unsigned)(excl & 0xFFFFFFFFull);
+        const unsigned new_id = acc.contrib + (unsigned)(excl >> 32);
         for (unsigned j = 0; j < cnt; ++j) {
             const unsigned pos = base + j;
-            if (pos >= max_vpl) break;
+            if (pos >= K.max_vpl) break;
             VplRec r = W.slots[(size_t)i * kGiBounces + j];
-            r.w[11] = new_id;
-            d_out[pos] = r;
-            if (pos + 1u == max_vpl) {   // the serial loop stops inside this path: it is the last one counted
-                s_acc.n_paths = first + i + 1u;
-                s_acc.done = 1u;
+            r.w[11] = new_id;   // LightArray::normalizeIntensity's renumbering: ids count the contributing paths
+            K.d_out[pos] = r;
+        }
+    }
+    if (timed_out && lane == 0u) *W.error = 2u;
+    // The records are in place in device memory.  Every wave checks out; the last one scales the set and writes it
+    // to the host in whole cache lines (records of different waves share lines: written to host memory from several
+    // XCDs at once, a line came out with one wave's bytes and another's stale ones).
+    __threadfence();
+    unsigned ticket = 0u;
+    if (lane == 0u) ticket = atomicAdd(K.barrier, 1u);
+    ticket = __shfl(ticket, 0);
+    if (ticket != K.epoch + 2u * n_w - 1u) return;
+    __threadfence();
+    acc.size += (unsigned)(grand & 0xFFFFFFFFull);
+    acc.contrib += (unsigned)(grand >> 32);
+    acc.error = __hip_atomic_load(W.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (acc.done && !acc.error) {
+        const unsigned* src = reinterpret_cast<const unsigned*>(K.d_out);
+        unsigned* dst = reinterpret_cast<unsigned*>(K.h_out);
+        const unsigned n_words = K.max_vpl * 24u;
+        for (unsigned k0 = 0; k0 < n_words; k0 += 64u * 8u) {
+            unsigned w[8];
+#pragma unroll
+            for (unsigned u = 0; u < 8u; ++u) {   // eight independent loads in flight per lane
+                const unsigned k = k0 + u * 64u + lane;
+                w[u] = k < n_words ? src[k] : 0u;
+            }
+#pragma unroll
+            for (unsigned u = 0; u < 8u; ++u) {
+                const unsigned k = k0 + u * 64u + lane;
+                const unsigned c = k % 24u;
+                if (c >= 4u && c < 7u) w[u] = __float_as_uint(__uint_as_float(w[u]) * inv);   // intensity (PointLight.h:68)
+                if (k < n_words) dst[k] = w[u];
             }
         }
-        if (i == 0u) {
-            s_acc.size += (unsigned)(total & 0xFFFFFFFFull);
-            s_acc.contrib += (unsigned)(total >> 32);
-            if (*W.error) s_acc.error = 1u;
-        }
-        phase_sync();
-        if (s_acc.done || s_acc.error) break;
-        first += nb;
     }
-    if (s_acc.done && !s_acc.error) {
-        const float inv = 1.0f / (float)(int)s_acc.n_paths;   // LightArray.hpp:47
-        for (unsigned k = i; k < max_vpl; k += (unsigned)kSmallBlock) {
-            VplRec r = d_out[k];
-            for (int c = 4; c < 7; ++c) r.w[c] = __float_as_uint(__uint_as_float(r.w[c]) * inv);
-            h_out[k] = r;
-        }
+    if (lane == 0u) {
+        *K.d_acc = acc;
+        *K.h_acc = acc;
+        *W.error = 0u;
     }
-    if (i == 0u) *h_acc = s_acc;
 }
 
 }  // namespace
@@ -511,12 +592,16 @@ extern "C" int gigl_photon_trace_batch(const gigl_scene* s, const gigl_fog* fog,
     const size_t o_mat = take((size_t)n_mat * 48);
     // the traversal launches' workspace (work counter + stack spill area), so that they neither allocate nor clear
     const unsigned trace_blocks = std::min<unsigned>(n_blocks, (unsigned)s->n_cus * 6u);
-    // a small set in one launch (photon_small_kernel): one workgroup of 1,024 lanes, whose traversal spills into
-    // the same workspace (1,024 lanes = 4 of the batched launches' 256-lane workgroups)
+    // a small set in one launch (photon_small_kernel)
     const int small_opt = option_photon_small();
-    const bool small = (unsigned)max_vpl_count <= kSmallMaxVpls && (small_opt == 1 || (small_opt < 0 && paths_per_batch == 0)) &&
-                       P >= (unsigned)kSmallBlock;
-    const size_t o_tws = take(trace_workspace_bytes(std::max<unsigned>(trace_blocks, kSmallBlock / 256)));
+    const bool small = (unsigned)max_vpl_count <= kSmallMaxVpls && P <= kSmallMaxPaths &&
+                       (small_opt == 1 || (small_opt < 0 && paths_per_batch == 0));
+    // its spill area: one 64-lane workgroup per 64 paths = P / 256 of the batched launches' 256-lane workgroups
+    const size_t o_tws = take(trace_workspace_bytes(std::max<unsigned>(trace_blocks, 128u * 64u / 256u)));   // the one-launch route: at most 128 waves
+    // the barrier counter (64 B), per-wave work counters (2 words x 128 waves, from +64), per-wave totals (from
+    // +2048) and per-wave count masks (from +3072)
+    const size_t o_small = take(3072 + 128 * 16);
+    static_assert(kSmallMaxPaths == 128 * 32, "at most 128 waves of 32 paths per launch");
     // the workspace and the stream belong to the scene and are kept between calls (a 150-VPL set is a
     // dozen short launches: allocating per call would cost as much as the walk); calls on one scene serialise
     gigl_scene* ms = const_cast<gigl_scene*>(s);
@@ -527,7 +612,7 @@ extern "C" int gigl_photon_trace_batch(const gigl_scene* s, const gigl_fog* fog,
         ms->photon_mats.clear(); ms->photon_mats_at = nullptr;
         HIP_TRY(hipMalloc(&ms->photon_ws, off));
         ms->photon_ws_bytes = off;
-        ms->photon_ws_fresh = true;
+        ms->photon_small_at = nullptr;
     }
     char* const ws = (char*)ms->photon_ws;
     const hipStream_t st = ms->one_stream;
@@ -573,26 +658,56 @@ extern "C" int gigl_photon_trace_batch(const gigl_scene* s, const gigl_fog* fog,
             scene_trace_params(s, Q);
             Q.o_tmin = W.o_tmin; Q.d_tmax = W.d_tmax;
             Q.hits = (uint4*)(ws + o_hits); Q.ranges = (float2*)(ws + o_rng); Q.hit_tri = (float4*)(ws + o_tri);
-            Q.counter = (unsigned*)(ws + o_tws);
             Q.spill = (uint4*)(ws + o_tws + 256);
-            Q.spill_stride = (unsigned)kSmallBlock;
-            Q.refill_thresh = 24; Q.chunk = 64u; Q.guided = 0u; Q.t_exit = 20;
-            Q.reset_counter = 1u;   // the last wave out of every traversal leaves the counter at zero for the next bounce
-            // the counter words start at zero: the batched route's kernels and every traversal leave them so, and a
-            // fresh workspace is cleared here
-            if (ms->photon_ws_fresh) {
-                HIP_TRY(hipMemsetAsync(ws + o_tws, 0, 256, st));
-                ms->photon_ws_fresh = false;
+            // a wave of 8 to 32 rays: the T-phase runs until no lane descends any more (a threshold sized for 64 busy
+            // lanes would end it after every step): -3 %
+            Q.refill_thresh = 24; Q.chunk = 64u; Q.guided = 0u; Q.t_exit = 1;
+            SmallParams K = {};
+            K.max_vpl = (unsigned)max_vpl_count;
+            K.d_out = d_out;
+            K.h_out = (VplRec*)ms->photon_h_dev;
+            K.d_acc = d_acc;
+            K.h_acc = (Acc*)((char*)ms->photon_h_dev + (size_t)kSmallMaxVpls * sizeof(VplRec));
+            K.barrier = (unsigned*)(ws + o_small);
+            K.wg_masks = (unsigned long long*)(ws + o_small + 3072);
+            K.counters = (unsigned*)(ws + o_small + 64);
+            K.wg_totals = (unsigned long long*)(ws + o_small + 2048);
+            // the barrier counter only grows (every launch adds two arrivals per wave; the host keeps count); a new
+            // workspace, or one whose layout moved with another block size, starts from zero, and so does the error
+            // word, which wave 0 clears again after reading it
+            if (ms->photon_small_at != ws + o_small) {
+                HIP_TRY(hipMemsetAsync(ws + o_small, 0, 64, st));
+                HIP_TRY(hipMemsetAsync(W.error, 0, 4, st));
+                ms->photon_small_at = ws + o_small;
+                ms->photon_epoch = 0u;
             }
-            VplRec* h_out = (VplRec*)ms->photon_h_dev;
-            Acc* h_acc = (Acc*)((char*)ms->photon_h_dev + (size_t)kSmallMaxVpls * sizeof(VplRec));
+            K.lanes = P <= 1024u ? 8u : (P <= 2048u ? 16u : 32u);   // at most 128 waves per launch
             auto kern = s->triples ? photon_small_kernel<true> : photon_small_kernel<false>;
-            hipLaunchKernelGGL(kern, dim3(1), dim3(kSmallBlock), 0, st, W, Q, (unsigned)max_vpl_count, (unsigned)path_limit,
-                               d_out, h_out, h_acc);
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipStreamSynchronize(st));
-            std::memcpy(&acc, (char*)ms->photon_h + (size_t)kSmallMaxVpls * sizeof(VplRec), sizeof(Acc));
-            if (acc.error) return fail(GIGL_ERR_INVALID, "a hit triangle names a material beyond n_mat");
+            const Acc* h_acc = (const Acc*)((char*)ms->photon_h + (size_t)kSmallMaxVpls * sizeof(VplRec));
+            uint64_t first = 0;
+            while (first < path_limit) {
+                const unsigned nb = (unsigned)std::min<uint64_t>(P, path_limit - first);
+                const unsigned grid = (nb + K.lanes - 1u) / K.lanes;
+                W.first = (unsigned)first; W.n = nb;
+                Q.spill_stride = grid * 64u;
+                K.epoch = ms->photon_epoch;
+                ms->photon_epoch += 2u * grid;
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, st, W, Q, K);
+                hipError_t le = hipGetLastError();
+                if (le == hipSuccess) le = hipStreamSynchronize(st);
+                if (le != hipSuccess) {
+                    ms->photon_small_at = nullptr;   // the counter is no longer where the host thinks it is
+                    return fail(GIGL_ERR_HIP, std::string("photon_small_kernel: ") + hipGetErrorString(le));
+                }
+                std::memcpy(&acc, h_acc, sizeof(Acc));
+                if (acc.error == 2u) {
+                    ms->photon_small_at = nullptr;
+                    return fail(GIGL_ERR_HIP, "photon_small_kernel: the waves of the launch did not all arrive at its barrier");
+                }
+                if (acc.error) return fail(GIGL_ERR_INVALID, "a hit triangle names a material beyond n_mat");
+                if (acc.done) break;
+                first += nb;
+            }
             if (!acc.done) {   // :181-184
                 std::memset(vpls_out, 0, (size_t)max_vpl_count * sizeof(VplRec));
                 if (n_paths_out) *n_paths_out = (uint32_t)path_limit;

@@ -255,6 +255,7 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
     unsigned* const my_stack0 = s_stack0 + tid;
     uint4* const my_spill = P.spill + ((size_t)blockIdx.x * BLOCK + tid);
     const uint4* __restrict__ recs = P.recs;
+    const float4* __restrict__ tris = P.tris;
 
     RayReg r;
     float root_tmax = 0.0f;
@@ -323,7 +324,7 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
             if (P.ranges) {   // gigl_trace_one: the ray's range as KdTree::intersect leaves it, and the hit triangle
                 P.ranges[ray_idx] = make_float2(r.tmin, r.tmax);
                 if (P.hit_tri && hit) {
-                    const float4* t = P.tris + kTriStride * (size_t)best_id;
+                    const float4* t = tris + kTriStride * (size_t)best_id;
                     P.hit_tri[3 * ray_idx] = t[0]; P.hit_tri[3 * ray_idx + 1] = t[1]; P.hit_tri[3 * ray_idx + 2] = t[2];
                 }
             }
@@ -548,8 +549,8 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
                     }
                 }
                 if (!two) id1 = id0;
-                const TriRec t0 = load_tri(tri_ptr(P.tris, in_block ? id0 : id0 * (kTriStride * 2u)));
-                const TriRec t1 = load_tri(tri_ptr(P.tris, in_block ? id1 : id1 * (kTriStride * 2u)));
+                const TriRec t0 = load_tri(tri_ptr(tris, in_block ? id0 : id0 * (kTriStride * 2u)));
+                const TriRec t1 = load_tri(tri_ptr(tris, in_block ? id1 : id1 * (kTriStride * 2u)));
                 bool hit = tri_test(t0, t0.tag, r, best_t, best_u, best_v, best_id);
                 if (!(ANY && hit) && two) hit = tri_test(t1, t1.tag, r, best_t, best_u, best_v, best_id) || hit;
                 any_done = ANY && hit;
