@@ -21,6 +21,11 @@
 #ifndef GIGL_EPS_ALU
 #define GIGL_EPS_ALU 1
 #endif
+// LDS stack entries per lane of the default launches (12 bytes each; deeper entries spill to global memory).
+// 8 with 6 waves per SIMD is the shipped pair; 7 / 7 and 6 / 8 are the occupancy experiments of DESIGN.md §4.1.
+#ifndef GIGL_LDS_STACK
+#define GIGL_LDS_STACK 8
+#endif
 #ifndef GIGL_STREAM_HINT
 #define GIGL_STREAM_HINT 1
 #endif

@@ -31,7 +31,7 @@ using namespace gd;
 namespace {
 
 #if GIGL_WAVES_PER_EU
-#define GIGL_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(STACK_N == 8 ? GIGL_WAVES_PER_EU : 1, 8)))
+#define GIGL_WAVES_ATTR __attribute__((amdgpu_waves_per_eu((STACK_N == 8 || STACK_N == GIGL_LDS_STACK) ? GIGL_WAVES_PER_EU : 1, 8)))
 #else
 #define GIGL_WAVES_ATTR
 #endif
@@ -368,8 +368,8 @@ template <bool ANY, int GEN, int STACK_N, int BLOCK = kBlock>
 int launch_trace_t(const gigl_scene* s, TraceParams& P, const Options& opt, hipStream_t st, const ExtWorkspace* ext) {
     auto kern = s->triples ? trace_kernel<true, ANY, GEN, STACK_N, BLOCK> : trace_kernel<false, ANY, GEN, STACK_N, BLOCK>;
     // instrumented builds: explicit-ray closest-hit with the default LDS stack only
-    const bool stats = !ANY && GEN == 0 && STACK_N == 8 && BLOCK == kBlock && opt.stats && !ext;
-    if (stats) kern = s->triples ? trace_kernel<true, ANY, GEN, 8, BLOCK, true> : trace_kernel<false, ANY, GEN, 8, BLOCK, true>;
+    const bool stats = !ANY && GEN == 0 && (STACK_N == 8 || STACK_N == GIGL_LDS_STACK) && BLOCK == kBlock && opt.stats && !ext;
+    if (stats) kern = s->triples ? trace_kernel<true, ANY, GEN, STACK_N, BLOCK, true> : trace_kernel<false, ANY, GEN, STACK_N, BLOCK, true>;
     unsigned grid;
     if (ext) {
         grid = ext->max_grid;
@@ -397,7 +397,7 @@ int launch_trace_t(const gigl_scene* s, TraceParams& P, const Options& opt, hipS
     const bool spill = STACK_N < 32 && s->tree.actual_depth - 1 > STACK_N;
     void* ws = nullptr;
     if (ext) {
-        static_assert(STACK_N >= 8, "the external spill area holds 32 - 8 entries per lane");
+        if (STACK_N < 8) return fail(GIGL_ERR_INVALID, "the external spill area holds 32 - 8 entries per lane");
         ws = ext->base;
     } else {
         const size_t spill_entries = spill ? (size_t)grid * BLOCK * (size_t)(32 - STACK_N) : 0;
@@ -513,7 +513,9 @@ int launch_trace(const gigl_scene* s, TraceParams& P, hipStream_t st, const ExtW
     else if (deepest <= 12 && sn >= 12) sn = 12;
     else if (deepest <= 16 && sn >= 16) sn = 16;
     if (rc == GIGL_OK) switch (sn) {
-        case 8: rc = launch_trace_t<ANY, GEN, 8>(s, P, opt, st, ext); break;
+        // GIGL_LDS_STACK (build switch, default 8): the depth the default launches run with; launches on a caller's
+        // workspace keep 8, which their spill areas are sized for
+        case 8: rc = ext ? launch_trace_t<ANY, GEN, 8>(s, P, opt, st, ext) : launch_trace_t<ANY, GEN, GIGL_LDS_STACK>(s, P, opt, st, ext); break;
         case 12: rc = launch_trace_t<ANY, GEN, 12>(s, P, opt, st, ext); break;
         case 16: rc = launch_trace_t<ANY, GEN, 16>(s, P, opt, st, ext); break;
         case 32: rc = launch_trace_t<ANY, GEN, 32>(s, P, opt, st, ext); break;
@@ -1234,7 +1236,7 @@ int gigl_debug_launch_info(const gigl_scene* s, int* blocks_per_cu, int* n_cus) 
     if (!s || !blocks_per_cu || !n_cus) return fail(GIGL_ERR_INVALID, "NULL argument");
     if (s->device == GIGL_DEVICE_NONE) return fail(GIGL_ERR_NO_DEVICE, "host-only scene");
     DeviceGuard g(s->device);
-    auto kern = s->triples ? trace_kernel<true, false, 0, 8, kBlock> : trace_kernel<false, false, 0, 8, kBlock>;
+    auto kern = s->triples ? trace_kernel<true, false, 0, GIGL_LDS_STACK, kBlock> : trace_kernel<false, false, 0, GIGL_LDS_STACK, kBlock>;
     int q = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, kern, kBlock, 0));
     *blocks_per_cu = q;
