@@ -26,6 +26,10 @@
 #ifndef GIGL_LDS_STACK
 #define GIGL_LDS_STACK 8
 #endif
+// 1: explicit-ray closest-hit launches run the kernel in which rays change lanes (trace_body's XCHG); experiment
+#ifndef GIGL_XCHG
+#define GIGL_XCHG 0
+#endif
 #ifndef GIGL_STREAM_HINT
 #define GIGL_STREAM_HINT 1
 #endif
@@ -245,6 +249,8 @@ struct TraceParams {
     float4* hit_tri;             // optional, with ranges: the first 48 bytes of the hit triangle's record per ray
     unsigned reset_counter;      // kept workspaces: the last wave out zeroes the counter words (counter[0] work, counter[1] waves out)
     const unsigned* perm;        // optional (GEN 0): work item i traces ray perm[i] (ray regrouping)
+    int xchg_min;                // XCHG kernels: a wave runs a phase for at least this many lanes (or for the larger group)
+    unsigned xchg_every;         // XCHG kernels: the waves of a workgroup exchange rays every this many rounds (>= 1)
 };
 
 // ---- 3-vectors for the shading stage (operation order as the oracle's V3) ------------------

@@ -35,9 +35,9 @@ namespace {
 #else
 #define GIGL_WAVES_ATTR
 #endif
-template <bool TRIPLES, bool ANY, int GEN, int STACK_N, int BLOCK, bool STATS = false>
+template <bool TRIPLES, bool ANY, int GEN, int STACK_N, int BLOCK, bool STATS = false, bool XCHG = false>
 __global__ void __launch_bounds__(BLOCK) GIGL_WAVES_ATTR trace_kernel(const TraceParams P) {
-    trace_body<TRIPLES, ANY, GEN, STACK_N, BLOCK, STATS>(P);   // gigl_trace_body.h
+    trace_body<TRIPLES, ANY, GEN, STACK_N, BLOCK, STATS, XCHG>(P);   // gigl_trace_body.h
 }
 
 // ---- ray regrouping: coarse counting sort by (direction octant, Morton cell of the origin) -----
@@ -249,6 +249,9 @@ struct Options {
                               // side by side); the output layout is the same
     int build_threads = 0;    // read at gigl_scene_create: host threads of the tree build (0: min(16, cores)); the
                               // tree does not depend on it
+    int xchg_every = 1;       // GIGL_XCHG builds: rounds between two exchanges of rays among the waves of a workgroup (0: the
+                              // ordinary kernel)
+    int xchg_min = 1;         // GIGL_XCHG builds: smallest group of lanes a wave runs a phase for (1: every phase runs)
     int photon_small = -1;    // gigl_photon_trace_batch: 1 sets of up to 1,024 VPLs run as one workgroup in one launch
                               // (gigl_photon.hip, photon_small_kernel), 0 never, -1 the engine's choice: when the
                               // caller leaves paths_per_batch to the engine
@@ -370,6 +373,17 @@ int launch_trace_t(const gigl_scene* s, TraceParams& P, const Options& opt, hipS
     // instrumented builds: explicit-ray closest-hit with the default LDS stack only
     const bool stats = !ANY && GEN == 0 && (STACK_N == 8 || STACK_N == GIGL_LDS_STACK) && BLOCK == kBlock && opt.stats && !ext;
     if (stats) kern = s->triples ? trace_kernel<true, ANY, GEN, STACK_N, BLOCK, true> : trace_kernel<false, ANY, GEN, STACK_N, BLOCK, true>;
+    bool xchg = false;
+#if GIGL_XCHG
+    if constexpr (!ANY && GEN == 0 && BLOCK == kBlock && STACK_N == GIGL_LDS_STACK) {
+        if (s->triples && !ext && opt.xchg_every > 0) {
+            xchg = true;
+            kern = stats ? trace_kernel<true, false, 0, STACK_N, BLOCK, true, true> : trace_kernel<true, false, 0, STACK_N, BLOCK, false, true>;
+            P.xchg_every = (unsigned)opt.xchg_every;
+            P.xchg_min = opt.xchg_min;
+        }
+    }
+#endif
     unsigned grid;
     if (ext) {
         grid = ext->max_grid;
@@ -378,8 +392,8 @@ int launch_trace_t(const gigl_scene* s, TraceParams& P, const Options& opt, hipS
         if (per_cu <= 0) {
             // one cache per instantiation (this function is a template), layout and instrumented build;
             // the devices of a node are identical, so it is not keyed by device
-            static std::atomic<int> cached[4] = {{0}, {0}, {0}, {0}};
-            std::atomic<int>& c = cached[(stats ? 2 : 0) + (s->triples ? 1 : 0)];
+            static std::atomic<int> cached[8] = {{0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}};
+            std::atomic<int>& c = cached[(xchg ? 4 : 0) + (stats ? 2 : 0) + (s->triples ? 1 : 0)];
             int q = c.load(std::memory_order_relaxed);
             if (q <= 0) {
                 HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, kern, BLOCK, 0));
@@ -724,6 +738,12 @@ int gigl_set_option(const char* name, int value) {
     } else if (k == "build_threads") {
         if (value < 0 || value > 256) return fail(GIGL_ERR_INVALID, "build_threads must be in 0..256");
         g_opt.build_threads = value;
+    } else if (k == "xchg_every") {
+        if (value < 0 || value > 64) return fail(GIGL_ERR_INVALID, "xchg_every must be in 0..64");
+        g_opt.xchg_every = value;
+    } else if (k == "xchg_min") {
+        if (value < 1 || value > 64) return fail(GIGL_ERR_INVALID, "xchg_min must be in 1..64");
+        g_opt.xchg_min = value;
     } else if (k == "photon_small") {
         if (value < -1 || value > 1) return fail(GIGL_ERR_INVALID, "photon_small must be -1, 0 or 1");
         g_opt.photon_small = value;

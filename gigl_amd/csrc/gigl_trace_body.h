@@ -223,13 +223,25 @@ __device__ __forceinline__ void spill_load(const uint4* p, unsigned& a, unsigned
 // a record still to be loaded (unit = w1 >> 3).
 //
 // A lane without a ray always holds a leaf, so the T-phase test needs no have_ray term.
-template <bool TRIPLES, bool ANY, int GEN, int STACK_N, int BLOCK, bool STATS = false>
+//
+// XCHG (experiment, closest-hit over explicit rays, 256-lane workgroups): rays change lanes.  Every P.xchg_every
+// rounds the four waves of a workgroup meet and, lane column by lane column (lane l of waves 0..3), hand their
+// rays round so that the descending ones end up in the low waves and the ones at leaves in the high waves: a wave
+// then runs its T-phase, or its L-phase, with most of its lanes.  A ray's traversal stack does not move: the ray
+// carries a slot number (the wave and lane whose LDS column and spill area it was given) — the bank a stack access
+// falls into depends on the lane alone, so the accesses stay conflict free.  What moves is the register state,
+// 24 dwords per ray, through one 4 KB transient buffer in six passes.
+template <bool TRIPLES, bool ANY, int GEN, int STACK_N, int BLOCK, bool STATS = false, bool XCHG = false>
 __device__ __forceinline__ void trace_body(const TraceParams& P) {
+    static_assert(!XCHG || (TRIPLES && !ANY && GEN == 0 && BLOCK == 256), "the exchange is built for one configuration");
     // stack entry = (t_split, the far child's two words): the far child is in registers when the
     // entry is pushed, so a pop costs no global load (pairs) or at most the record's (triples)
     __shared__ uint2 s_stack[STACK_N * BLOCK];     // (t_split, w1)
     __shared__ unsigned s_stack0[STACK_N * BLOCK]; // w0
     __shared__ float s_eps[kEpsTable];
+    __shared__ uint4 s_xbuf[XCHG ? BLOCK : 1];      // XCHG: four dwords of every lane's state at a time
+    __shared__ unsigned s_xcls[XCHG ? 64 : 1];      // XCHG: per lane column, one class byte per wave
+    __shared__ unsigned s_xalive[XCHG ? 4 : 1];     // XCHG: per wave, whether it still has rays or may get some
     const unsigned tid = threadIdx.x;
     const unsigned lane = tid & 63u;
     for (int i = (int)tid; i < kEpsTable; i += BLOCK) s_eps[i] = eps_from_exp(i - kEpsBias + 1);
@@ -251,9 +263,11 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
 #else
     auto eps_of = [&](float t) { return s_eps[(unsigned)(__builtin_amdgcn_frexp_expf(t) + kEpsBias)]; };
 #endif
-    uint2* const my_stack = s_stack + tid;
-    unsigned* const my_stack0 = s_stack0 + tid;
-    uint4* const my_spill = P.spill + ((size_t)blockIdx.x * BLOCK + tid);
+    // XCHG: `slot` travels with the ray (the lane a ray sits in changes, its stack's place does not)
+    unsigned slot = tid;
+    uint2* my_stack = s_stack + tid;
+    unsigned* my_stack0 = s_stack0 + tid;
+    uint4* my_spill = P.spill + ((size_t)blockIdx.x * BLOCK + tid);
     const uint4* __restrict__ recs = P.recs;
     const float4* __restrict__ tris = P.tris;
 
@@ -359,7 +373,8 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
     // STATS build only (tools/sweep.py stats=1): wave-level round counts and lane-level work counts
     const unsigned long long st_t0 = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;
     unsigned st_rounds = 0, st_t_iters = 0, st_t_lanes = 0, st_l_rounds = 0, st_l_lanes = 0, st_refills = 0,
-             st_refill_lanes = 0, st_rays_lanes = 0;
+             st_refill_lanes = 0, st_rays_lanes = 0, st_moved = 0;
+    unsigned xround = 0;   // XCHG: rounds of this wave; the four waves of a workgroup count alike
     const int t_exit = P.t_exit;
 
     // Per-lane state machine.  A lane with a ray is either Traversing (at an interior node) or at a
@@ -446,12 +461,69 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
                 pool_next = __builtin_amdgcn_readfirstlane(pool_next + take);
             }
         }
-        if (__ballot(have_ray) == 0ull) {
-            if (pool_empty) break;
-            continue;
+        if constexpr (XCHG) {
+            if (xround++ % P.xchg_every == 0u) {
+                // classes of this lane column: 0 descending, 1 no ray, 2 at a leaf
+                const unsigned w = tid >> 6;
+                const unsigned cls = have_ray ? (descending() ? 0u : 2u) : 1u;
+                reinterpret_cast<unsigned char*>(s_xcls)[lane * 4u + w] = (unsigned char)cls;
+                if (lane == 0u) s_xalive[w] = (__ballot(have_ray) != 0ull || !pool_empty) ? 1u : 0u;
+                __syncthreads();
+                const unsigned col = s_xcls[lane];
+                const unsigned alive = s_xalive[0] | s_xalive[1] | s_xalive[2] | s_xalive[3];
+                if (!alive) break;   // the same for all four waves: none has rays, none can get any
+                const unsigned c0 = col & 255u, c1 = (col >> 8) & 255u, c2 = (col >> 16) & 255u, c3 = col >> 24;
+                // stable sort of the column by class: where each wave's ray goes
+                const unsigned d0 = (c1 < c0) + (c2 < c0) + (c3 < c0);
+                const unsigned d1 = (c0 <= c1) + (c2 < c1) + (c3 < c1);
+                const unsigned d2 = (c0 <= c2) + (c1 <= c2) + (c3 < c2);
+                const unsigned src = d0 == w ? 0u : (d1 == w ? 1u : (d2 == w ? 2u : 3u));
+                const bool moved = src != w;
+                if (STATS && moved) ++st_moved;
+                const unsigned from = src * 64u + lane;
+                uint4 q;
+#define GIGL_XPASS(a, b, c, d)                                   \
+                q = make_uint4(a, b, c, d);                      \
+                s_xbuf[tid] = q;                                 \
+                __syncthreads();                                 \
+                if (moved) q = s_xbuf[from];                     \
+                __syncthreads();
+                GIGL_XPASS(__float_as_uint(r.ox), __float_as_uint(r.oy), __float_as_uint(r.oz), __float_as_uint(r.dx))
+                r.ox = __uint_as_float(q.x); r.oy = __uint_as_float(q.y); r.oz = __uint_as_float(q.z); r.dx = __uint_as_float(q.w);
+                GIGL_XPASS(__float_as_uint(r.dy), __float_as_uint(r.dz), __float_as_uint(r.ix), __float_as_uint(r.iy))
+                r.dy = __uint_as_float(q.x); r.dz = __uint_as_float(q.y); r.ix = __uint_as_float(q.z); r.iy = __uint_as_float(q.w);
+                GIGL_XPASS(__float_as_uint(r.iz), __float_as_uint(r.tmin), __float_as_uint(r.tmax), __float_as_uint(root_tmax))
+                r.iz = __uint_as_float(q.x); r.tmin = __uint_as_float(q.y); r.tmax = __uint_as_float(q.z); root_tmax = __uint_as_float(q.w);
+                GIGL_XPASS(__float_as_uint(best_t), __float_as_uint(best_u), __float_as_uint(best_v), best_id)
+                best_t = __uint_as_float(q.x); best_u = __uint_as_float(q.y); best_v = __uint_as_float(q.z); best_id = q.w;
+                GIGL_XPASS(rec.x, rec.y, rec.z, rec.w)
+                rec = q;
+                GIGL_XPASS(ray_idx, leaf_i, (unsigned)(sp + 1) | (lvl << 8) | ((have_ray ? 1u : 0u) << 9), slot)
+#undef GIGL_XPASS
+                ray_idx = q.x; leaf_i = q.y;
+                sp = (int)(q.z & 255u) - 1; lvl = (q.z >> 8) & 1u; have_ray = ((q.z >> 9) & 1u) != 0u;
+                slot = q.w;
+                my_stack = s_stack + slot;
+                my_stack0 = s_stack0 + slot;
+                my_spill = P.spill + ((size_t)blockIdx.x * BLOCK + slot);
+            }
+        } else {
+            if (__ballot(have_ray) == 0ull) {
+                if (pool_empty) break;
+                continue;
+            }
+        }
+        // XCHG: a phase that only a few lanes of this wave would take part in is left out; their rays wait for the
+        // next exchange, which hands them to a wave where they are many (the phase with more lanes always runs)
+        bool run_t = true, run_l = true;
+        if constexpr (XCHG) {
+            const int n_t = __popcll(__ballot(descending())), n_l = __popcll(__ballot(have_ray && !descending()));
+            run_t = n_t >= P.xchg_min || n_t >= n_l;
+            run_l = n_l >= P.xchg_min || n_l > n_t;
         }
         // ---- T-phase: KdTree.hpp:284-311 ----
         for (;;) {
+            if (XCHG && !run_t) break;
             const bool is_t = descending();
             const unsigned long long m_t = __ballot(is_t);
             if (m_t == 0ull) break;
@@ -497,7 +569,7 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
         }
         // ---- L-phase: KdTree.hpp:312-343.  Prims are tested in m_leaf_prim_ids order, two per
         // round; both triangles' loads are issued before the first test. ----
-        if (have_ray && !descending()) {
+        if (have_ray && !descending() && (!XCHG || run_l)) {
             unsigned n_prims;
             if constexpr (TRIPLES) {
                 if (lvl == 1u) {   // a leaf inside a record: its payload names the prims
@@ -601,7 +673,7 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
         atomicAdd(P.stats + 2, (unsigned long long)st_t_lanes);
         atomicAdd(P.stats + 3, (unsigned long long)st_l_rounds);
         atomicAdd(P.stats + 4, (unsigned long long)st_l_lanes);
-        atomicAdd(P.stats + 5, (unsigned long long)st_refills);
+        atomicAdd(P.stats + 5, (unsigned long long)(XCHG ? st_moved : st_refills));   // XCHG builds: lanes whose ray changed at an exchange
         atomicAdd(P.stats + 6, (unsigned long long)st_refill_lanes);
         atomicAdd(P.stats + 7, (unsigned long long)st_rays_lanes);
         // when the waves start and stop, on the 100 MHz real-time counter: the drain tail of the

@@ -2,7 +2,7 @@
 # Prints per-kernel register / LDS / scratch / occupancy figures for gigl_rt.hip (gfx950).
 cd "$(dirname "$0")"
 /opt/rocm/bin/hipcc -std=c++17 -O3 -ffp-contract=off -fno-fast-math --offload-arch=gfx950 --cuda-device-only -c \
-  -Rpass-analysis=kernel-resource-usage -o /tmp/gigl_rt_res.o ${1:-gigl_rt.hip} 2>&1 | python3 -c '
+  -Rpass-analysis=kernel-resource-usage -o /tmp/gigl_rt_res.o ${1:-gigl_rt.hip} $2 $3 $4 2>&1 | python3 -c '
 import sys,re
 cur={}
 for line in sys.stdin:
