@@ -126,8 +126,8 @@ def git_head():
         return None
 
 
-KERNEL_SOURCES = ["gigl_amd/csrc/gigl_rt.hip", "gigl_amd/csrc/gigl_internal.h", "gigl_amd/csrc/kd_layout.cpp",
-                  "gigl_amd/csrc/kd_layout.h"]
+KERNEL_SOURCES = ["gigl_amd/csrc/gigl_rt.hip", "gigl_amd/csrc/gigl_trace_body.h", "gigl_amd/csrc/gigl_internal.h",
+                  "gigl_amd/csrc/kd_layout.cpp", "gigl_amd/csrc/kd_layout.h"]
 
 
 def kernel_sources_hash():

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""profiles/traffic.json from the counter passes tools/prof_r03.sh took (condensed by tools/summarize_prof.py into
+profiles/<tag>_pmc.json and profiles/<tag>_s500_pmc.json), stamped with the hash of the kernel sources they were
+taken on.  usage: tools/make_traffic.py TAG [commit]"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+tag = sys.argv[1]
+commit = sys.argv[2] if len(sys.argv) > 2 else bench.git_head()
+path = os.path.join(ROOT, "profiles", "traffic.json")
+tj = json.load(open(path))
+N = float(1 << 24)
+for key, t, note in (("bounce", tag, "S(158), 2^24 rays, leaf blocks n>=6"),
+                     ("bounce_s500", tag + "_s500", "S(500), 2^24 rays, leaf blocks n>=2; scaled per ray for other batch sizes")):
+    f = os.path.join(ROOT, "profiles", "%s_pmc.json" % t)
+    if not os.path.exists(f):
+        print("missing", f)
+        continue
+    c = json.load(open(f))["counters"]
+    miss = c["TCC_MISS_sum"]["per_launch_mean"]
+    wr = c["WRITE_SIZE"]["per_launch_mean"] * 1024
+    ent = {"hbm_bytes_per_launch": miss * 128 + wr, "layout": 2, "source": "profiles/%s_pmc.json" % t, "commit": commit,
+           "fetch_size_bytes": c["FETCH_SIZE"]["per_launch_mean"] * 1024, "write_size_bytes": wr,
+           "tcc_miss_per_launch": miss, "tcc_miss_per_ray": miss / N, "note": note}
+    if "SQ_INSTS_VALU" in c:
+        ent["valu_insts_per_launch"] = c["SQ_INSTS_VALU"]["per_launch_mean"]
+        ent["valu_insts_per_pair"] = c["SQ_INSTS_VALU"]["per_launch_mean"] / N
+    tj[key] = ent
+    print(key, {k: (round(v, 3) if isinstance(v, float) else v) for k, v in ent.items()})
+tj["kernel_sources_sha256_16"] = bench.kernel_sources_hash()
+tj["kernel_sources"] = bench.KERNEL_SOURCES
+json.dump(tj, open(path, "w"), indent=1)
+print("stamped", tj["kernel_sources_sha256_16"])
