@@ -30,6 +30,10 @@
 #ifndef GIGL_XCHG
 #define GIGL_XCHG 0
 #endif
+// 1: the T-phase requests the line of the next records before it decides its two steps (experiment)
+#ifndef GIGL_EARLY_TOUCH
+#define GIGL_EARLY_TOUCH 0
+#endif
 #ifndef GIGL_STREAM_HINT
 #define GIGL_STREAM_HINT 1
 #endif

@@ -530,6 +530,15 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
             if (STATS) { ++st_t_iters; st_t_lanes += __popcll(m_t); }
             if (is_t) {
                 if constexpr (TRIPLES) {   // up to two levels and exactly one record load per lane and iteration
+#if GIGL_EARLY_TOUCH
+                    // Experiment: the four records one of which this iteration ends up loading share a 128-byte line
+                    // (kd_layout.cpp); one dword of it is requested before the two steps are decided, so that the
+                    // decisions' arithmetic overlaps the miss.  `touch` stays allocated until its data has arrived
+                    // (the s_waitcnt below names it): a load's destination register must not be reused in flight.
+                    unsigned touch = 0u;
+                    const bool touched = lvl == 0u;
+                    if (touched) asm volatile("global_load_dword %0, %1, off" : "=v"(touch) : "v"(recs + ((rec.w >> 6) << 1)));
+#endif
                     if (lvl == 0u) {   // a node with both children in its record: no load
                         const Step s = decide(rec.w & 3u, __uint_as_float(rec.x));
                         const unsigned type_a = (rec.w >> 2) & 3u, type_b = (rec.w >> 4) & 3u;
@@ -554,6 +563,9 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
                         rec = recs[blk + (s.take_top ? 1u : 0u)];
                         lvl = 0u;
                     }
+#if GIGL_EARLY_TOUCH
+                    if (touched) asm volatile("s_waitcnt vmcnt(0)" ::"v"(touch));
+#endif
                 } else {
                     // slot of the bottom child; the top child is the next slot
                     const uint4 kids = *reinterpret_cast<const uint4*>(P.nodes + (nd.y >> 2));
