@@ -281,6 +281,9 @@ def main():
     if world > 1 and not args.rebuild_per_rank:
         scene = rt.Scene(V, T, device=dev_index, **S.KD_PARAMS) if rank == 0 else None
         scene, replication = shard.replicate_scene(torch, dist, rt, scene, rank, device, backend=backend)
+        if scene is None:   # rank 0 could not offer its arrays: this rank builds its own tree after all
+            rt.set_option("build_threads", max(1, min(16, (os.cpu_count() or 1) // world)))
+            scene = rt.Scene(V, T, device=dev_index, **S.KD_PARAMS)
     else:
         scene = rt.Scene(V, T, device=dev_index, **S.KD_PARAMS)
     st = scene.stats()

@@ -168,32 +168,43 @@ def replicate_scene(torch, dist, rt, scene, rank, device, backend="nccl", src=0,
     direct = backend == "nccl"
     t0 = time.time()
     nhdr = ctypes.sizeof(rt.SceneBlob)
-    ptrs = [0, 0, 0]
+    views = [None, None, None]
+    hdr = torch.zeros(nhdr + 1, dtype=torch.uint8)   # last byte: rank src could offer its arrays
     if rank == src:
-        desc, ptrs = scene.export_device_blob()
-        hdr = torch.frombuffer(bytearray(bytes(desc)), dtype=torch.uint8).clone()
-    else:
-        hdr = torch.zeros(nhdr, dtype=torch.uint8)
+        try:   # nothing collective happens in here: a failure is told to the other ranks through the header
+            desc, ptrs = scene.export_device_blob()
+            for k, nb in enumerate((desc.nb_nodes, desc.nb_leaf_ids, desc.nb_tris)):
+                if nb:
+                    views[k] = torch.as_tensor(_DeviceBytes(ptrs[k], nb), device=device)
+            hdr[:nhdr] = torch.frombuffer(bytearray(bytes(desc)), dtype=torch.uint8)
+            hdr[nhdr] = 1
+        except Exception as e:   # noqa: BLE001
+            views = [None, None, None]
+            print("replicate_scene: rank %d cannot offer its arrays (%s); every rank builds its own tree" % (src, e), flush=True)
     if direct:
         hdr = hdr.to(device)
     dist.broadcast(hdr, src)
-    desc = rt.SceneBlob.from_buffer_copy(hdr.cpu().numpy().tobytes())
+    hdr = hdr.cpu()
+    if int(hdr[nhdr]) != 1:
+        return (scene if rank == src else None), {"how": "rank %d could not export its arrays: one build per rank" % src,
+                                                   "bytes": 0, "seconds": round(time.time() - t0, 3)}
+    desc = rt.SceneBlob.from_buffer_copy(hdr[:nhdr].numpy().tobytes())
+    piece = 1 << 30   # broadcasts of at most 1 GiB: no element count near 2^31 anywhere below
     arrays = []
     for k, nb in enumerate((desc.nb_nodes, desc.nb_leaf_ids, desc.nb_tris)):
         if nb == 0:
             arrays.append(None)
             continue
-        if rank == src:
-            t = torch.as_tensor(_DeviceBytes(ptrs[k], nb), device=device)
-        else:
-            t = torch.empty(int(nb), dtype=torch.uint8, device=device)
-        if direct:
-            dist.broadcast(t, src)
-        else:
-            c = t.cpu()
-            dist.broadcast(c, src)
-            if rank != src:
-                t.copy_(c)
+        t = views[k] if rank == src else torch.empty(int(nb), dtype=torch.uint8, device=device)
+        for lo in range(0, int(nb), piece):
+            part = t[lo:lo + piece]
+            if direct:
+                dist.broadcast(part, src)
+            else:
+                c = part.cpu()
+                dist.broadcast(c, src)
+                if rank != src:
+                    part.copy_(c)
         arrays.append(t)
     if rank != src:
         torch.cuda.synchronize(device)
@@ -207,7 +218,9 @@ def replicate_scene(torch, dist, rt, scene, rank, device, backend="nccl", src=0,
         ptr = lambda t: 0 if t is None else t.data_ptr()
         adopted = rt.Scene.from_device_blob(desc, ptr(arrays[0]), ptr(arrays[1]), ptr(arrays[2]), device=device.index,
                                             stream=torch.cuda.current_stream(device).cuda_stream)
-    del arrays
+    del arrays, views
+    if rank != src:
+        torch.cuda.empty_cache()   # the received copies: the scene holds its own
     info = {"how": "rank %d builds, header + 3 device arrays broadcast over %s, other ranks adopt them (no rebuild)" % (src, backend),
             "bytes": int(desc.nb_nodes + desc.nb_leaf_ids + desc.nb_tris), "seconds": round(time.time() - t0, 3)}
     if adopted is not None:
