@@ -11,9 +11,10 @@ namespace {
 
 __global__ void __launch_bounds__(256) transm_segments_kernel(FogParams F, const float4* seg_p,
                                                               const float4* seg_d, unsigned n, float* out) {
+    GIGL_FOG_LUT_DECL
     for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
         const float4 p = seg_p[i], d = seg_d[i];
-        out[i] = calc_transm(F, p.x, p.y, p.z, d.x, d.y, d.z, d.w);
+        out[i] = calc_transm<GIGL_FOG_LUT != 0>(F, p.x, p.y, p.z, d.x, d.y, d.z, d.w, s_unorm);
     }
 }
 
@@ -23,6 +24,7 @@ __global__ void __launch_bounds__(256) transm_segments_kernel(FogParams F, const
 __global__ void __launch_bounds__(256) pi_density_kernel(FogParams F, Cam12 cam, unsigned res_x, unsigned n_pix,
                                                          const uint4* __restrict__ hits, float* __restrict__ out) {
     const BoxF fb = {F.mnx, F.mny, F.mnz, F.mxx, F.mxy, F.mxz};
+    GIGL_FOG_LUT_DECL
     for (unsigned p = blockIdx.x * 256u + threadIdx.x; p < n_pix; p += gridDim.x * 256u) {
         RayReg r;
         float dx, dy, dz;
@@ -39,7 +41,7 @@ __global__ void __launch_bounds__(256) pi_density_kernel(FogParams F, Cam12 cam,
             const float ivx = F.mxx - F.mnx, ivy = F.mxy - F.mny, ivz = F.mxz - F.mnz;
             auto dens_at = [&](float t) {
                 const float qx = r.ox + t * r.dx, qy = r.oy + t * r.dy, qz = r.oz + t * r.dz;
-                return fog_filter(F, (qx - F.mnx) / ivx, (qy - F.mny) / ivy, (qz - F.mnz) / ivz);  // computeNormPos
+                return fog_filter<GIGL_FOG_LUT != 0>(F, (qx - F.mnx) / ivx, (qy - F.mny) / ivy, (qz - F.mnz) / ivz, s_unorm);  // computeNormPos
             };
             float prev = dens_at(t_min), dens = 0.0f;
             for (int i = 1; i <= n_intervals; ++i) {

@@ -34,6 +34,20 @@
 #ifndef GIGL_EARLY_TOUCH
 #define GIGL_EARLY_TOUCH 0
 #endif
+// 1: the ray-march kernels (nine or 257 samples per lane, bound by vector-ALU issue) read byte / 255.0f from a
+// 256-entry table in LDS instead of computing it: 152 M Cornell segments 4.16 -> 3.94 ms (+5.6 %)
+#ifndef GIGL_FOG_LUT
+#define GIGL_FOG_LUT 1
+#endif
+// the table, filled by a 256-lane workgroup from the same function it replaces
+#if GIGL_FOG_LUT
+#define GIGL_FOG_LUT_DECL                               \
+    __shared__ float s_unorm[256];                      \
+    s_unorm[threadIdx.x] = gd::byte_unorm(threadIdx.x); \
+    __syncthreads();
+#else
+#define GIGL_FOG_LUT_DECL const float* s_unorm = nullptr;
+#endif
 #ifndef GIGL_STREAM_HINT
 #define GIGL_STREAM_HINT 1
 #endif
@@ -155,7 +169,10 @@ __device__ __forceinline__ float byte_unorm(unsigned b) {
 }
 __device__ __forceinline__ float lerp1(float p0, float p1, float t) { return (1.0f - t) * p0 + t * p1; }
 // DensityField.cpp:180-201 from a normalized position; lerp order x, y, z (Interpolation.hpp:8-23)
-__device__ __forceinline__ float fog_filter(const FogParams& F, float nx, float ny, float nz) {
+// LUT: `lut` is a 256-entry table of byte_unorm in LDS (kernels that take nine samples per lane and are bound by
+// vector-ALU issue: a table read replaces four of the five instructions per texel, exact by construction).
+template <bool LUT = false>
+__device__ __forceinline__ float fog_filter(const FogParams& F, float nx, float ny, float nz, const float* lut = nullptr) {
     const float tcx = nx * (float)F.rx - 0.5f, tcy = ny * (float)F.ry - 0.5f, tcz = nz * (float)F.rz - 0.5f;
     const float fx = floorf(tcx), fy = floorf(tcy), fz = floorf(tcz);
     const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
@@ -168,10 +185,11 @@ __device__ __forceinline__ float fog_filter(const FogParams& F, float nx, float 
     // 32-bit index: gigl_fog_create keeps the brick count below 2^31
     if ((bx <= (unsigned)F.rx) & (by <= (unsigned)F.ry) & (bz <= (unsigned)F.rz))
         w = F.bricks[bx + (by + bz * (unsigned)(F.ry + 1)) * (unsigned)(F.rx + 1)];
-    const float d000 = byte_unorm(w.x & 0xFFu), d100 = byte_unorm((w.x >> 8) & 0xFFu);
-    const float d010 = byte_unorm((w.x >> 16) & 0xFFu), d110 = byte_unorm(w.x >> 24);
-    const float d001 = byte_unorm(w.y & 0xFFu), d101 = byte_unorm((w.y >> 8) & 0xFFu);
-    const float d011 = byte_unorm((w.y >> 16) & 0xFFu), d111 = byte_unorm(w.y >> 24);
+    auto un = [&](unsigned b) { return LUT ? lut[b] : byte_unorm(b); };
+    const float d000 = un(w.x & 0xFFu), d100 = un((w.x >> 8) & 0xFFu);
+    const float d010 = un((w.x >> 16) & 0xFFu), d110 = un(w.x >> 24);
+    const float d001 = un(w.y & 0xFFu), d101 = un((w.y >> 8) & 0xFFu);
+    const float d011 = un((w.y >> 16) & 0xFFu), d111 = un(w.y >> 24);
     const float i0 = lerp1(lerp1(d000, d100, tx), lerp1(d010, d110, tx), ty);
     const float i1 = lerp1(lerp1(d001, d101, tx), lerp1(d011, d111, tx), ty);
     return lerp1(i0, i1, tz);
@@ -181,8 +199,9 @@ __device__ __forceinline__ float smin(float x, float y) { return y < x ? y : x; 
 __device__ __forceinline__ float smax(float x, float y) { return x < y ? y : x; }
 
 // calcTransm + intersectBBox + rayMarch, Surface.frag:139-203
+template <bool LUT = false>
 __device__ __forceinline__ float calc_transm(const FogParams& F, float px, float py, float pz, float wx, float wy,
-                                             float wz, float dist_sq) {
+                                             float wz, float dist_sq, const float* lut = nullptr) {
     if (!(F.ext_k > 0.0f)) return 1.0f;
     const float max_dist = sqrtf(dist_sq);
     const float ivx = 1.0f / wx, ivy = 1.0f / wy, ivz = 1.0f / wz;
@@ -200,7 +219,7 @@ __device__ __forceinline__ float calc_transm(const FogParams& F, float px, float
     const float dt = (t_max - t_min) / (float)F.n_intervals;
     auto ext_at = [&](float t) {
         const float qx = px + t * wx, qy = py + t * wy, qz = pz + t * wz;
-        return F.ext_k * fog_filter(F, (qx - F.mnx) * idx, (qy - F.mny) * idy, (qz - F.mnz) * idz);
+        return F.ext_k * fog_filter<LUT>(F, (qx - F.mnx) * idx, (qy - F.mny) * idy, (qz - F.mnz) * idz, lut);
     };
     float prev = ext_at(t_min), total = 0.0f;
     for (int i = 1; i <= F.n_intervals; ++i) {

@@ -153,10 +153,11 @@ __global__ void __launch_bounds__(256) shadow_points_kernel(TraceParams P, unsig
 }
 
 __global__ void __launch_bounds__(256) transm_shadow_kernel(FogParams F, TraceParams P, float* out) {
+    GIGL_FOG_LUT_DECL
     for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < P.n; i += gridDim.x * 256u) {
         ShadowSeg s;
         float tr = 1.0f;
-        if (shadow_segment(P, i, s)) tr = calc_transm(F, s.px, s.py, s.pz, s.wx, s.wy, s.wz, s.dist_sq);
+        if (shadow_segment(P, i, s)) tr = calc_transm<GIGL_FOG_LUT != 0>(F, s.px, s.py, s.pz, s.wx, s.wy, s.wz, s.dist_sq, s_unorm);
         out[i] = tr;
     }
 }
@@ -170,6 +171,7 @@ constexpr unsigned kVisPairsPerWave = 2048;
 __global__ void __launch_bounds__(256) transm_visible_kernel(FogParams F, TraceParams P, const unsigned long long* bits,
                                                              float* out) {
     __shared__ unsigned s_q[4][128];
+    GIGL_FOG_LUT_DECL
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     unsigned* q = s_q[wave];
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -177,7 +179,7 @@ __global__ void __launch_bounds__(256) transm_visible_kernel(FogParams F, TraceP
     auto march = [&](unsigned idx) {
         ShadowSeg s;
         float tr = 1.0f;   // points whose primary ray missed
-        if (shadow_segment(P, idx, s)) tr = calc_transm(F, s.px, s.py, s.pz, s.wx, s.wy, s.wz, s.dist_sq);
+        if (shadow_segment(P, idx, s)) tr = calc_transm<GIGL_FOG_LUT != 0>(F, s.px, s.py, s.pz, s.wx, s.wy, s.wz, s.dist_sq, s_unorm);
         out[idx] = tr;
     };
     for (unsigned blk = blockIdx.x * 4u + wave; blk < n_blocks; blk += gridDim.x * 4u) {

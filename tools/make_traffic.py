@@ -32,6 +32,17 @@ for key, t, note in (("bounce", tag, "S(158), 2^24 rays, leaf blocks n>=6"),
         ent["valu_insts_per_pair"] = c["SQ_INSTS_VALU"]["per_launch_mean"] / N
     tj[key] = ent
     print(key, {k: (round(v, 3) if isinstance(v, float) else v) for k, v in ent.items()})
+import re
+for key, pairs in (("cornell_shadow", 152059200), ("transmittance", 152059200)):   # 1,013,728 hit pixels x 150 golden VPLs
+    f = os.path.join(ROOT, "profiles", "%s_%s_counters.txt" % (tag.split("_")[0], key))
+    if not os.path.exists(f):
+        print("missing", f)
+        continue
+    m = re.search(r"SQ_INSTS_VALU\s+([0-9.e+]+) per launch", open(f).read())
+    v = float(m.group(1))
+    tj[key] = {"valu_insts_per_launch": v, "pairs": pairs, "valu_insts_per_pair": v / pairs,
+               "source": "profiles/%s_%s_counters.txt (tools/prof_extras_r03.sh)" % (tag.split("_")[0], key), "commit": commit}
+    print(key, tj[key])
 tj["kernel_sources_sha256_16"] = bench.kernel_sources_hash()
 tj["kernel_sources"] = bench.KERNEL_SOURCES
 json.dump(tj, open(path, "w"), indent=1)
