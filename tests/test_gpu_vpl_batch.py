@@ -136,3 +136,11 @@ def test_default_route_is_one_launch_for_the_reference_sized_set(setup):
     rt.set_option("photon_small", 1)
     (n, want, want_paths), (g_n, got, got_paths) = _both(setup, 1, 1000, 9)
     assert g_n == n == 1000 and got_paths == want_paths > 2048 and np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("n_vpls", [1, 7, 1024, 1025])
+def test_set_sizes_at_the_edges_of_the_one_launch_route(setup, n_vpls):
+    """One record (100 paths at most, PhotonTracer.cpp:180), the largest set the one-launch kernel takes, and the first
+    size beyond it (batched under either setting of the option)."""
+    (n, want, want_paths), (g_n, got, got_paths) = _both(setup, 1, n_vpls, 31337 + n_vpls)
+    assert g_n == n == n_vpls and got_paths == want_paths and np.array_equal(got, want)

@@ -46,6 +46,17 @@ for seed in range(first, first + n_scenes):
                 rt.set_option("any_atomic", mode)
                 ok = ok and np.array_equal(gpu.trace(ro, rd, is_vis_ray=True), occ)
             rt.set_option("any_atomic", -1)
+            if ok and layout in (2, 3) and stack_lds == 8:
+                # round 3: the same scene through a device list that repeats device 0 (replication, scatter, gather;
+                # host-pointer ranges on worker threads) and through a scene adopted from its flattened device arrays
+                m = rt.MultiDeviceScene(gpu, [0, 0, 0])
+                ok = ok and np.array_equal(m.trace(ro, rd).view(np.uint32), got.view(np.uint32))
+                ok = ok and np.array_equal(m.trace_any(ro, rd).astype(bool), occ)
+                m.close()
+                desc, ptrs = gpu.export_device_blob()
+                rep = rt.Scene.from_device_blob(desc, ptrs[0], ptrs[1], ptrs[2], device=0)
+                ok = ok and np.array_equal(rep.trace(ro, rd).view(np.uint32), got.view(np.uint32))
+                rep.close()
             if not ok:
                 bad += 1
                 print("MISMATCH seed %d layout %d stack %d tris %d %s %r" % (seed, layout, stack_lds, n_tris, flavour, params),
