@@ -228,13 +228,20 @@ namespace {
 
 struct Options {
     int stack_lds = 8;        // LDS entries per lane (12 bytes each): 8, 12, 16 or 32; 8 keeps 6 workgroups per CU
-    int refill_thresh = 24;   // idle lanes that trigger a refill (closest-hit / atomic any-hit)
+    int refill_thresh = 0;    // idle lanes that trigger a refill (closest-hit / atomic any-hit), 1..64; 0: the engine's choice:
+                              // 24, or 40 on a tiny scene (see chunk)
     int any_atomic = -1;      // 0: any-hit waves own 64 consecutive rays, one store per wave; 1: lane refill +
                               // atomicOr; -1: the engine's choice (1)
     int blocks_per_cu = 0;    // 0: occupancy query
     int chunk = 0;            // rays per work-counter atomic; 0: the engine's choice (256; 512 for structures served
-                              // from HBM, where a wave's rays live twice as long: +1.6 % on S(500), -2 % on S(158))
-    int guided = 4;           // 0: fixed chunks; k: near the end a request is remaining / (k * waves)
+                              // from HBM, where a wave's rays live twice as long: +1.6 % on S(500), -2 % on S(158);
+                              // 1,024 on a tiny scene — a structure of at most 1 MB, resident in every cache: its rays are
+                              // so cheap that the waves' requests saturate the one counter they all go through (152 M
+                              // Cornell shadow pairs: 76 requests per us in chunks of 256 against the ~88 per us one word
+                              // serves).  Chunks of 1,024, no shrinking requests near the end, refills at 40 idle lanes:
+                              // 7.88 -> 5.36 ms, profiles/r03_knob_sweep_cornell_shadow.txt)
+    int guided = -1;          // 0: fixed chunks; k: near the end a request is remaining / (k * waves); -1: the engine's choice:
+                              // 4, or 0 on a tiny scene (see chunk)
     int t_exit = 20;          // see trace_kernel: T-phase exit threshold (1..64)
     int stats = 0;            // 1: closest-hit launches run the instrumented build and keep 8 counters
     int sort_rays = 0;        // explicit-ray batches: 1 regroup rays before tracing, 0 never, -1 deep tree + large
@@ -505,16 +512,21 @@ int launch_trace(const gigl_scene* s, TraceParams& P, hipStream_t st, const ExtW
         // light-major needs every lane to write its own bit (atomicOr mode) and both counts to fit the index maths
         if (!(ANY && P.any_atomic && opt.shadow_order == 1 && P.n_lights > 1u)) P.n_pts = 0u;
     }
+    const bool tiny_scene = s->stats.device_bytes <= ((uint64_t)1 << 20);
+    if (opt.refill_thresh <= 0) opt.refill_thresh = tiny_scene ? 40 : 24;
+    if (opt.guided < 0) opt.guided = tiny_scene ? 0 : 4;
     P.refill_thresh = (ANY && !P.any_atomic) ? 64 : opt.refill_thresh;
     if (P.refill_thresh < 1) P.refill_thresh = 1;
     if (P.refill_thresh > 64) P.refill_thresh = 64;
-    P.chunk = opt.chunk > 0 ? (unsigned)opt.chunk : (s->stats.device_bytes > ((uint64_t)256 << 20) ? 512u : 256u);
+    P.chunk = opt.chunk > 0 ? (unsigned)opt.chunk
+                            : (s->stats.device_bytes > ((uint64_t)256 << 20) ? 512u : (tiny_scene ? 1024u : 256u));
     if (opt.chunk <= 0) {
         // a batch that is small against the machine: smaller requests, so that every resident wave gets some
         // (2^18 rays in requests of 256 would occupy a sixth of the waves, four rays deep per lane: 0.81 ms
         // against 0.63), but no more requests than about 4/3 per wave: they all go through one counter, and
         // cheap coherent rays are bound by it (1024^2 Cornell primary rays: 0.28 ms in requests of 64, 0.17 in 256)
-        const uint64_t max_requests = (uint64_t)s->n_cus * 32u;
+        // (half as many on a tiny scene, whose rays are cheap everywhere: 1024^2 Cornell primary rays then keep 256)
+        const uint64_t max_requests = (uint64_t)s->n_cus * (tiny_scene ? 16u : 32u);
         while (P.chunk > 64u && (uint64_t)P.n <= max_requests * (P.chunk / 2u)) P.chunk >>= 1;
     }
     P.t_exit = opt.t_exit;
@@ -703,7 +715,7 @@ int gigl_set_option(const char* name, int value) {
             return fail(GIGL_ERR_INVALID, "stack_lds must be 8, 12, 16 or 32");
         g_opt.stack_lds = value;
     } else if (k == "refill_thresh") {
-        if (value < 1 || value > 64) return fail(GIGL_ERR_INVALID, "refill_thresh must be in 1..64");
+        if (value < 0 || value > 64) return fail(GIGL_ERR_INVALID, "refill_thresh must be in 0..64");
         g_opt.refill_thresh = value;
     } else if (k == "any_atomic") {
         if (value < -1 || value > 1) return fail(GIGL_ERR_INVALID, "any_atomic must be -1, 0 or 1");
@@ -729,7 +741,7 @@ int gigl_set_option(const char* name, int value) {
         if (value != 0 && (value < 64 || value > 65536 || value % 64)) return fail(GIGL_ERR_INVALID, "chunk must be 0 or a multiple of 64 in 64..65536");
         g_opt.chunk = value;
     } else if (k == "guided") {
-        if (value < 0 || value > 64) return fail(GIGL_ERR_INVALID, "guided must be in 0..64");
+        if (value < -1 || value > 64) return fail(GIGL_ERR_INVALID, "guided must be in -1..64");
         g_opt.guided = value;
     } else if (k == "leaf_blocks") {
         if (value < -1 || value == 1 || value > 64) return fail(GIGL_ERR_INVALID, "leaf_blocks must be -1, 0 or 2..64");

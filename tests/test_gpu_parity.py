@@ -134,12 +134,12 @@ def test_launch_options_do_not_change_results(s16, stack_lds, refill, any_atomic
         assert np.array_equal(occ.astype(bool), want["tri_id"] != rt.GIGL_MISS)
     finally:
         rt.set_option("stack_lds", 8)
-        rt.set_option("refill_thresh", 24)
+        rt.set_option("refill_thresh", 0)
         rt.set_option("any_atomic", -1)
         rt.set_option("t_exit", 20)
         rt.set_option("sort_rays", 0)
         rt.set_option("sort_bits", 6)
-        rt.set_option("guided", 4)
+        rt.set_option("guided", -1)
         rt.set_option("chunk", 0)
 
 

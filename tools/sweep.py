@@ -74,7 +74,7 @@ def main():
     hits = torch.empty((n, 4), dtype=torch.int32, device=dev)
     bits = torch.zeros((n + 63) // 64, dtype=torch.int64, device=dev)
     sh = torch.cuda.current_stream().cuda_stream
-    defaults = {"stack_lds": 8, "refill_thresh": 24, "any_atomic": -1, "blocks_per_cu": 0, "chunk": 0, "t_exit": 20, "sort_rays": 0, "sort_bits": 6, "guided": 4, "xchg_every": 1, "xchg_min": 1}
+    defaults = {"stack_lds": 8, "refill_thresh": 0, "any_atomic": -1, "blocks_per_cu": 0, "chunk": 0, "t_exit": 20, "sort_rays": 0, "sort_bits": 6, "guided": -1, "xchg_every": 1, "xchg_min": 1}
     res = {v: [] for v in a.variants}
     ref_hits = None
     for r in range(a.rounds + 1):
