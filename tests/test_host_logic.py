@@ -245,7 +245,9 @@ def _counter_constants(bench, t):
     assert bench.line_rate_info(None, None, 1, 1.0) is None
     for key in ("bounce", "bounce_s500", "cornell_shadow", "transmittance"):
         v = bench.valu_roofline(key, 1 << 24, 5.0)
-        assert v and 0 < v["frac"] and v["peak"] == bench.VALU_PEAK_GINST
+        # the peak is priced from the kernel's instruction mix: between the 4-cycle and the 2-cycle class
+        assert v and 0 < v["frac"] and bench.VALU_PEAK_GINST <= v["peak"] <= bench.VALU_PEAK_FAST_GINST
+        assert abs(v["peak"] - bench.SIMD_GCYCLES / v["mean_cycles_per_inst"]) < 0.1
         assert os.path.exists(os.path.join(ROOT, v["source"].split()[0])), v["source"]
     assert bench.valu_roofline("no such entry", 1, 1.0) is None
     # counter constants are quoted only for the kernel sources they were taken on

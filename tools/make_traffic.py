@@ -9,6 +9,23 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import valu_mix  # noqa: E402
+
+KERNELS = {"bounce": "trace_kernel<true, false, 0, 8, 256, false, false>",
+           "bounce_s500": "trace_kernel<true, false, 0, 8, 256, false, false>",
+           "cornell_shadow": "trace_kernel<true, true, 2, 8, 256, false, false>",
+           "transmittance": "transm_shadow_kernel"}
+
+
+def mix(key):
+    """Static vector-ALU mix of the kernel (tools/valu_mix.py): the mean issue cost bench.py prices an instruction at."""
+    k = valu_mix.static_mix(KERNELS[key])[0]
+    return {"valu_static_mix": {"kernel": k["name"], "instructions": k["n"],
+                                "by_cycles": {str(c): v for c, v in sorted(k["by_cost"].items())},
+                                "mean_cycles": round(k["mean_cycles"], 3),
+                                "source": "tools/valu_mix.py on this tree; issue costs from profiles/r03_valu_issue.txt"}}
+
 
 tag = sys.argv[1]
 commit = sys.argv[2] if len(sys.argv) > 2 else bench.git_head()
@@ -30,6 +47,7 @@ for key, t, note in (("bounce", tag, "S(158), 2^24 rays, leaf blocks n>=6"),
     if "SQ_INSTS_VALU" in c:
         ent["valu_insts_per_launch"] = c["SQ_INSTS_VALU"]["per_launch_mean"]
         ent["valu_insts_per_pair"] = c["SQ_INSTS_VALU"]["per_launch_mean"] / N
+        ent.update(mix(key))
     tj[key] = ent
     print(key, {k: (round(v, 3) if isinstance(v, float) else v) for k, v in ent.items()})
 import re
@@ -42,6 +60,7 @@ for key, pairs in (("cornell_shadow", 152059200), ("transmittance", 152059200)):
     v = float(m.group(1))
     tj[key] = {"valu_insts_per_launch": v, "pairs": pairs, "valu_insts_per_pair": v / pairs,
                "source": "profiles/%s_%s_counters.txt (tools/prof_extras_r03.sh)" % (tag.split("_")[0], key), "commit": commit}
+    tj[key].update(mix(key))
     print(key, tj[key])
 tj["kernel_sources_sha256_16"] = bench.kernel_sources_hash()
 tj["kernel_sources"] = bench.KERNEL_SOURCES
