@@ -270,7 +270,7 @@ struct Options {
 };
 Options g_opt;
 std::mutex g_opt_mu;
-unsigned long long g_last_stats[12] = {0};
+unsigned long long g_last_stats[kStatsWords] = {0};   // [0..11] the counters, [16...] the timeline histograms
 
 // ---- the no-allocation entry point's scratch (gigl_trace_closest_noalloc_device) ----------------
 // A file-scope device array: every GPU the library runs on holds its own copy, at its own address,
@@ -418,20 +418,22 @@ int launch_trace_t(const gigl_scene* s, TraceParams& P, const Options& opt, hipS
     if (grid > need) grid = need;
     if (grid == 0) return GIGL_OK;
     const bool spill = STACK_N < 32 && s->tree.actual_depth - 1 > STACK_N;
+    // workspace: 256 bytes (work counter, finish ticket; instrumented builds: counters and timeline behind them), spill area
+    const size_t hdr = stats ? ((128 + sizeof(g_last_stats) + 255) & ~(size_t)255) : 256;
     void* ws = nullptr;
     if (ext) {
         if (STACK_N < 8) return fail(GIGL_ERR_INVALID, "the external spill area holds 32 - 8 entries per lane");
         ws = ext->base;
     } else {
         const size_t spill_entries = spill ? (size_t)grid * BLOCK * (size_t)(32 - STACK_N) : 0;
-        HIP_TRY(gd::pool_alloc(s->device, &ws, 256 + spill_entries * sizeof(uint4), st));
+        HIP_TRY(gd::pool_alloc(s->device, &ws, hdr + spill_entries * sizeof(uint4), st));
     }
-    if (!P.reset_counter && !(ext && ext->counter_is_zero) && hipMemsetAsync(ws, 0, 256, st) != hipSuccess) {
+    if (!P.reset_counter && !(ext && ext->counter_is_zero) && hipMemsetAsync(ws, 0, hdr, st) != hipSuccess) {
         if (!ext) (void)hipFreeAsync(ws, st);
         return fail(GIGL_ERR_HIP, "hipMemsetAsync(workspace)");
     }
     P.counter = (unsigned*)ws;
-    P.spill = (uint4*)((char*)ws + 256);
+    P.spill = (uint4*)((char*)ws + hdr);
     P.spill_stride = grid * BLOCK;
     // guided requests only for batches that are long against the machine: a small batch would run
     // on minimum-size requests from its first ray (one atomic round trip per refill)
@@ -703,6 +705,13 @@ int gigl_debug_last_stats(uint64_t out[12]) {
     if (!out) return fail(GIGL_ERR_INVALID, "out is NULL");
     std::lock_guard<std::mutex> lk(g_opt_mu);
     for (int i = 0; i < 12; ++i) out[i] = g_last_stats[i];
+    return GIGL_OK;
+}
+
+int gigl_debug_last_timeline(uint64_t out[3072]) {
+    if (!out) return fail(GIGL_ERR_INVALID, "out is NULL");
+    std::lock_guard<std::mutex> lk(g_opt_mu);
+    for (unsigned i = 0; i < 3u * 1024u; ++i) out[i] = g_last_stats[kStatsTimeline + i];
     return GIGL_OK;
 }
 

@@ -231,6 +231,11 @@ __device__ __forceinline__ void spill_load(const uint4* p, unsigned& a, unsigned
 // carries a slot number (the wave and lane whose LDS column and spill area it was given) — the bank a stack access
 // falls into depends on the lane alone, so the accesses stay conflict free.  What moves is the register state,
 // 24 dwords per ray, through one 4 KB transient buffer in six passes.
+// STATS builds: the 12 counters of gigl_debug_last_stats sit at P.stats[0..11]; three 1024-bucket histograms over the
+// 100 MHz real-time counter (rays started, rounds, lanes holding a ray at a round; of every 16th wave) follow at P.stats[16...]
+constexpr unsigned kStatsTimeline = 16u;
+constexpr unsigned kStatsWords = kStatsTimeline + 3u * 1024u;
+
 template <bool TRIPLES, bool ANY, int GEN, int STACK_N, int BLOCK, bool STATS = false, bool XCHG = false>
 __device__ __forceinline__ void trace_body(const TraceParams& P) {
     static_assert(!XCHG || (TRIPLES && !ANY && GEN == 0 && BLOCK == 256), "the exchange is built for one configuration");
@@ -374,6 +379,18 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
     const unsigned long long st_t0 = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;
     unsigned st_rounds = 0, st_t_iters = 0, st_t_lanes = 0, st_l_rounds = 0, st_l_lanes = 0, st_refills = 0,
              st_refill_lanes = 0, st_rays_lanes = 0, st_moved = 0;
+    // timeline (every 16th wave, so that the histogram's atomics do not slow the launch down): per-bucket sums kept in
+    // registers and flushed when the real-time counter enters the next 82 us bucket
+    const bool st_sampled = STATS && P.stats && (((blockIdx.x * (BLOCK / 64u) + (tid >> 6)) & 15u) == 0u);
+    unsigned st_bucket = STATS ? ((unsigned)(st_t0 >> 13) & 1023u) : 0u, st_b_started = 0, st_b_rounds = 0, st_b_lanes = 0;
+    auto st_flush = [&]() {
+        if (lane == 0 && st_b_rounds) {
+            atomicAdd(P.stats + kStatsTimeline + st_bucket, (unsigned long long)st_b_started);
+            atomicAdd(P.stats + kStatsTimeline + 1024u + st_bucket, (unsigned long long)st_b_rounds);
+            atomicAdd(P.stats + kStatsTimeline + 2048u + st_bucket, (unsigned long long)st_b_lanes);
+        }
+        st_b_started = 0; st_b_rounds = 0; st_b_lanes = 0;
+    };
     unsigned xround = 0;   // XCHG: rounds of this wave; the four waves of a workgroup count alike
     const int t_exit = P.t_exit;
 
@@ -385,7 +402,14 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
     for (;;) {
         const unsigned long long idle = __ballot(!have_ray);
         const int n_idle = __popcll(idle);
-        if (STATS) { ++st_rounds; st_rays_lanes += 64 - n_idle; }
+        if (STATS) {
+            ++st_rounds; st_rays_lanes += 64 - n_idle;
+            if (st_sampled) {   // timeline: rounds and lanes holding a ray per 82 us of the real-time counter
+                const unsigned b = (unsigned)(__builtin_amdgcn_s_memrealtime() >> 13) & 1023u;
+                if (b != st_bucket) { st_flush(); st_bucket = b; }
+                ++st_b_rounds; st_b_lanes += 64 - n_idle;
+            }
+        }
         if (n_idle >= P.refill_thresh && !pool_empty) {
             if (STATS) { ++st_refills; st_refill_lanes += n_idle; }
             if (group_mode) {
@@ -459,6 +483,7 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
                     }
                 }
                 pool_next = __builtin_amdgcn_readfirstlane(pool_next + take);
+                if (STATS && st_sampled) st_b_started += take;
             }
         }
         if constexpr (XCHG) {
@@ -679,6 +704,7 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
             P.counter[0] = 0u;
         }
     }
+    if (STATS && st_sampled) st_flush();
     if (STATS && lane == 0 && P.stats) {
         atomicAdd(P.stats + 0, (unsigned long long)st_rounds);
         atomicAdd(P.stats + 1, (unsigned long long)st_t_iters);

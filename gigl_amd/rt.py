@@ -25,7 +25,7 @@ SYMBOLS = [
     "gigl_trace_any_device", "gigl_trace_any", "gigl_trace_one", "gigl_camera_setup",
     "gigl_gen_primary_rays_device", "gigl_trace_primary_device", "gigl_shadow_batch_device", "gigl_fog_create",
     "gigl_fog_destroy", "gigl_transmittance_device", "gigl_sample_density", "gigl_debug_rescaled_eps",
-    "gigl_set_option", "gigl_debug_last_stats", "gigl_compute_pi_density_device", "gigl_shade_surface_device",
+    "gigl_set_option", "gigl_debug_last_stats", "gigl_debug_last_timeline", "gigl_compute_pi_density_device", "gigl_shade_surface_device",
     "gigl_tonemap_device", "gigl_volume_samples_device", "gigl_shadow_points_device", "gigl_shade_volume_device",
     "gigl_depth_buffer_device", "gigl_combine_device", "gigl_debug_check_layout", "gigl_scene_layout",
     "gigl_trace_closest_noalloc_device", "gigl_multi_create", "gigl_multi_destroy", "gigl_multi_device_count",
@@ -123,6 +123,7 @@ def lib():
         L.gigl_debug_rescaled_eps.argtypes = [i, vp, u64, vp]
         L.gigl_set_option.argtypes = [C.c_char_p, i]
         L.gigl_debug_last_stats.argtypes = [vp]
+        L.gigl_debug_last_timeline.argtypes = [vp]
         L.gigl_debug_check_layout.argtypes = [vp, i, i, vp]
         L.gigl_compute_pi_density_device.argtypes = [vp, vp, vp, i, i, vp, vp]
         L.gigl_shade_surface_device.argtypes = [vp, vp, vp, vp, vp, vp, u64, vp, u32, vp, vp, vp, vp, vp, vp, vp, vp]
@@ -170,6 +171,17 @@ def debug_pool_allocs():
 
 def set_option(name, value):
     _check(lib().gigl_set_option(name.encode(), int(value)))
+
+
+def debug_last_timeline():
+    """(rays started, rounds, ray-holding lanes over rounds) per 81.92 us bucket of the last instrumented launch (every 16th wave),
+    rotated so that bucket 0 holds the first wave's start; (3, 1024) uint64."""
+    out = np.zeros(3 * 1024, np.uint64)
+    _check(lib().gigl_debug_last_timeline(_p(out)))
+    st = np.zeros(12, np.uint64)
+    _check(lib().gigl_debug_last_stats(_p(st)))
+    t0 = (~int(st[8])) & 0xFFFFFFFFFFFFFFFF
+    return np.roll(out.reshape(3, 1024), -((t0 >> 13) & 1023), axis=1)
 
 
 def debug_last_stats():

@@ -371,6 +371,12 @@ int gigl_debug_check_layout(const gigl_scene* s, int layout, int treelet_levels,
  * 100 MHz real-time counter: ~(earliest wave start), latest wave end, sum of wave ends, waves. */
 int gigl_debug_last_stats(uint64_t out[12]);
 
+/* The same launch over time: three histograms of 1024 buckets of 81.92 us of the 100 MHz real-time counter,
+ * fed by every 16th wave (bucket = (t >> 13) & 1023, so they wrap after 84 ms; gigl_debug_last_stats' earliest start says where
+ * the launch begins): rays handed to lanes, rounds of all waves, lanes holding a ray summed over those
+ * rounds.  Shows the ramp, the steady state and the drain of one launch (tools/timeline.py). */
+int gigl_debug_last_timeline(uint64_t out[3072]);
+
 /* Residency of the explicit-ray closest-hit kernel of this scene's layout: 256-thread workgroups per
  * CU as the occupancy query reports them (= waves per SIMD: 4 waves per workgroup over 4 SIMDs), and
  * the CU count the persistent grid is sized with.  Diagnostic; bench.py reports it. */

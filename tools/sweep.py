@@ -115,6 +115,14 @@ def main():
                 print("   T-phase lane utilisation %.3f, L-phase %.3f, lanes holding a ray %.3f, T iters/round %.2f" % (
                     st["t_lane_steps"] / max(1, 64 * st["t_iters"]), st["l_lane_rounds"] / max(1, 64 * st["l_rounds"]),
                     st["ray_lane_rounds"] / max(1, 64 * st["rounds"]), st["t_iters"] / max(1, st["rounds"])), flush=True)
+                tl = rt.debug_last_timeline()
+                last = int(np.nonzero(tl[1])[0].max()) + 1 if tl[1].any() else 0
+                print("   timeline of every 16th wave, 81.92 us buckets from the first wave's start: Mrays started (x16) | rounds | mean lanes holding a ray at a round", flush=True)
+                step = max(1, last // 48)
+                for b in range(0, last, step):
+                    started = tl[0, b:b + step].sum(); rounds = tl[1, b:b + step].sum(); lanes = tl[2, b:b + step].sum()
+                    print("   %7.2f ms  %8.3f  %8d  %5.1f  %s" % (b * 0.08192, 16 * started / 1e6, rounds, lanes / max(1, rounds),
+                                                               "#" * int(round(40.0 * started / max(1, tl[0].max() * step)))), flush=True)
             if not pseudo["any"] and not pseudo["sorted"]:
                 h = hits.cpu().numpy()
                 if ref_hits is None:
