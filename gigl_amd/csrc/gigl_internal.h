@@ -31,6 +31,9 @@
 #define GIGL_XCHG 0
 #endif
 // 1: the T-phase requests the line of the next records before it decides its two steps (experiment)
+#ifndef GIGL_POP_TOUCH
+#define GIGL_POP_TOUCH 0   // 1: request the next pop's record when a leaf's triangle tests start (experiment)
+#endif
 #ifndef GIGL_EARLY_TOUCH
 #define GIGL_EARLY_TOUCH 0
 #endif

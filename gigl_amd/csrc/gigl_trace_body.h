@@ -628,6 +628,18 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
                 if (m_l) { ++st_l_rounds; st_l_lanes += __popcll(m_l); }
             }
             if (leaf_i < n_prims) {
+#if GIGL_POP_TOUCH
+                // Experiment: a lane that starts testing a leaf's triangles requests the record its next pop will load
+                // (the top stack entry names it), so that the pop's miss overlaps the triangle loads and tests.  One dword
+                // into `touch`, which stays allocated until the triangle data, requested after it, has arrived.
+                unsigned touch = 0u;
+                if constexpr (TRIPLES) {
+                    if (leaf_i == 0u && sp >= 0 && sp < STACK_N) {
+                        const unsigned w1n = my_stack[sp * BLOCK].y;
+                        if (w1n & 4u) asm volatile("global_load_dword %0, %1, off" : "=v"(touch) : "v"(recs + (w1n >> 3)));
+                    }
+                }
+#endif
                 unsigned id0 = 0u, id1 = 0u;   // table mode: triangle ids; block mode: record offsets in 8-byte units
                 const bool two = leaf_i + 1 < n_prims;
                 bool in_block = false;
@@ -664,6 +676,9 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
                 if (!(ANY && hit) && two) hit = tri_test(t1, t1.tag, r, best_t, best_u, best_v, best_id) || hit;
                 any_done = ANY && hit;
                 leaf_i += 2;
+#if GIGL_POP_TOUCH
+                asm volatile("" ::"v"(touch));
+#endif
             }
             if (any_done) {
                 finish(true);
