@@ -34,6 +34,9 @@
 #ifndef GIGL_POP_TOUCH
 #define GIGL_POP_TOUCH 0   // 1: request the next pop's record when a leaf's triangle tests start (experiment)
 #endif
+#ifndef GIGL_PHOTON_STAMPS
+#define GIGL_PHOTON_STAMPS 0   // 1: photon_small_kernel stamps its phases on the real-time counter (GIGL_PHOTON_TIMING=1 prints them)
+#endif
 #ifndef GIGL_EARLY_TOUCH
 #define GIGL_EARLY_TOUCH 0
 #endif
@@ -344,6 +347,7 @@ struct gigl_scene {
     size_t photon_ws_bytes = 0;
     unsigned photon_epoch = 0;           // the one-launch route's barrier count
     const void* photon_small_at = nullptr;   // where in photon_ws the one-launch route's ticket word was last cleared
+    float photon_rate = 4.0f;            // small sets: paths a kept record costs, learnt from the sets made so far (sizes the launch)
     void* photon_h = nullptr;            // small sets (one launch): page-locked, device-mapped staging the kernel writes
     void* photon_h_dev = nullptr;        // records and totals into (host address / the same memory as the device sees it)
     std::vector<float> photon_mats;      // the materials last uploaded into photon_ws, and where

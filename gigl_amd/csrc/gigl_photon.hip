@@ -17,6 +17,7 @@
 // float arithmetic of the reference in the reference's order (-ffp-contract=off).
 #include <cstring>
 
+#include <chrono>
 #include "gigl_trace_body.h"   // the traversal body: photon_small_kernel walks the tree itself
 
 using namespace gd;
@@ -378,17 +379,18 @@ __global__ void __launch_bounds__(256) vpl_normalize_kernel(VplRec* out, unsigne
 // ---- a whole small set in one launch ---------------------------------------------------------------
 // The batched route above is a chain of a dozen dependent launches and a read-back per block of paths:
 // 0.21 ms for the reference's own 150-VPL set.  For blocks of up to kSmallMaxPaths paths one launch does
-// everything: a workgroup is ONE wave that walks 8 to 32 paths on its first lanes (the fewer paths a wave holds,
+// everything: a workgroup is ONE wave that walks 4 to 32 paths on its first lanes (the fewer paths a wave holds,
 // the fewer rounds its divergent loops take, and up to 128 such waves spread over the chip; none of them waits
-// for another during the walk); per bounce the wave walks the tree itself (trace_body, the same traversal code as
-// every other query, fed from the wave's own rays through a work counter of its own), then every lane advances
+// for another during the walk); per bounce the wave walks the tree itself (trace_body in its SOLO form: the same
+// traversal code as every other query, its batch the wave's own rays, no work counter), then every lane advances
 // its path.  The ordered gather: the waves publish their record counts and meet at one barrier in global memory;
-// behind it every wave knows where its records go and places them; the last wave to check out scales the set
-// (LightArray::normalizeIntensity, LightArray.hpp:46-66) and writes it and the totals straight into page-locked
-// host memory.  One launch, one synchronisation, no copy.  Same arithmetic, same order of records: byte-identical
-// to the batched route.  What a set costs is then one wave's dependent chain: three tree walks of about 10 us
-// (the walk of the longest of its rays, some 4,000 instructions issued one every 4-5 cycles: walking the scene
-// from a copy in LDS changed nothing) and three path steps of about 5 us.
+// behind it every wave knows where its records go and what 1 / n_paths is (LightArray::normalizeIntensity,
+// LightArray.hpp:46-66), and writes its own records, scaled, straight into the page-locked host set; the last wave
+// to check out adds the totals and raises a flag in host memory, which the host call polls instead of waiting for
+// the launch to retire.  One launch, no copy.  Same arithmetic, same order of records: byte-identical to the
+// batched route.  What a set costs is then the slowest wave's dependent chain (GIGL_PHOTON_STAMPS=1 builds stamp it:
+// three tree walks of 10-17 us each — a lone wave issues an instruction every 8-13 cycles — three path steps of
+// 6-8 us, 5-10 us behind the barrier for the placement), 75-85 us in all against 35 us for the average wave.
 constexpr unsigned kSmallMaxPaths = 4096;   // 128 waves: their totals are scanned by one wave, two per lane
 constexpr unsigned kSmallMaxVpls = 1024;    // records the page-locked staging holds
 
@@ -438,6 +440,11 @@ struct SmallParams {
     unsigned long long* wg_masks;    // per wave: bit 0 and bit 1 of the record count of each of its paths
     unsigned* counters;              // two words per wave: its traversal work counter
     unsigned lanes;                  // paths per wave: 8, 16, 32 (or 64)
+#if GIGL_PHOTON_STAMPS
+    unsigned long long* stamps;      // 16 real-time stamps per wave (diagnostic build)
+#endif
+    unsigned* h_flag;                // page-locked host word: the last wave writes `token` once the set and the totals are out
+    unsigned token;
 };
 
 template <bool TRIPLES>
@@ -446,6 +453,13 @@ __global__ void __launch_bounds__(64) photon_small_kernel(const WalkParams W, co
     // divergent loops (tree walk, Woodcock tracking) per wave, and the waves have the whole chip to spread over
     const unsigned L = K.lanes;
     const unsigned g = blockIdx.x, lane = threadIdx.x;
+#if GIGL_PHOTON_STAMPS
+    unsigned n_st = 0;
+#define STAMP() do { if (lane == 0u) K.stamps[g * 16u + n_st] = __builtin_amdgcn_s_memrealtime(); ++n_st; } while (0)
+#else
+#define STAMP() do {} while (0)
+#endif
+    STAMP();
     const unsigned nb = W.n;
     const bool mine_path = lane < L && g * L + lane < nb;
     const unsigned i = mine_path ? g * L + lane : 0u;
@@ -455,12 +469,14 @@ __global__ void __launch_bounds__(64) photon_small_kernel(const WalkParams W, co
     Q.n = nb - g * L < L ? nb - g * L : L;
     Q.counter = K.counters + 2u * g;
     if (mine_path) path_start(W, i);
+    STAMP();
     for (int b = 1; b <= kGiBounces; ++b) {
-        if (lane == 0u) Q.counter[0] = 0u;
         phase_fence();
-        trace_body<TRIPLES, false, 0, 8, 64>(Q);
+        trace_body<TRIPLES, false, 0, 8, 64, false, false, true>(Q, b > 1);
         phase_fence();
+        STAMP();
         if (mine_path) path_bounce(W, i, b == kGiBounces ? 1 : 0);
+        STAMP();
     }
     // ---- the ordered gather (vpl_gather_kernel's), every wave placing its own records ----
     // The waves of a launch (at most 128 single-wave workgroups: all resident at once) meet once at a barrier in
@@ -476,7 +492,9 @@ __global__ void __launch_bounds__(64) photon_small_kernel(const WalkParams W, co
         K.wg_masks[2u * g] = b0;
         K.wg_masks[2u * g + 1u] = b1;
     }
+    STAMP();
     const bool timed_out = grid_barrier(K.barrier, K.epoch + gridDim.x, lane);
+    STAMP();
     const unsigned n_w = gridDim.x;
     const unsigned long long t0 = lane < n_w ? __hip_atomic_load(K.wg_totals + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
     const unsigned long long t1 = lane + 64u < n_w ? __hip_atomic_load(K.wg_totals + lane + 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
@@ -505,6 +523,11 @@ __global__ void __launch_bounds__(64) photon_small_kernel(const WalkParams W, co
         acc.n_paths = W.first + gd * L + (unsigned)__ffsll((long long)md);   // path index + 1 (PhotonTracer.cpp:115, :159, :180)
         inv = 1.0f / (float)(int)acc.n_paths;   // LightArray.hpp:47
     }
+    // The usual case, a set that this first launch completes: every wave knows 1 / n_paths and writes its records,
+    // scaled, to the page-locked host set itself (the staging is uncached on the device side, so records of
+    // different waves may share a line).  Otherwise the records collect in device memory over the launches and the
+    // last wave of the launch that completes the set scales and copies them.
+    const bool direct = acc.done && W.first == 0u;
     {
         const unsigned long long excl = before + incl - mine;
         const unsigned base = acc.size + (unsigned)(excl & 0xFFFFFFFFull);
@@ -514,14 +537,20 @@ __global__ void __launch_bounds__(64) photon_small_kernel(const WalkParams W, co
             if (pos >= K.max_vpl) break;
             VplRec r = W.slots[(size_t)i * kGiBounces + j];
             r.w[11] = new_id;   // LightArray::normalizeIntensity's renumbering: ids count the contributing paths
-            K.d_out[pos] = r;
+            if (direct) {   // intensity / n_paths (PointLight.h:68), straight into the host's set
+#pragma unroll
+                for (unsigned c = 4u; c < 7u; ++c) r.w[c] = __float_as_uint(__uint_as_float(r.w[c]) * inv);
+                K.h_out[pos] = r;
+            } else {
+                K.d_out[pos] = r;
+            }
         }
     }
     if (timed_out && lane == 0u) *W.error = 2u;
-    // The records are in place in device memory.  Every wave checks out; the last one scales the set and writes it
-    // to the host in whole cache lines (records of different waves share lines: written to host memory from several
-    // XCDs at once, a line came out with one wave's bytes and another's stale ones).
-    __threadfence();
+    STAMP();
+    // The records are in place.  Every wave checks out (what it wrote to the host is out, system scope, before its
+    // ticket); the last one writes the totals and, for a set that took several launches, scales and copies it.
+    __threadfence_system();
     unsigned ticket = 0u;
     if (lane == 0u) ticket = atomicAdd(K.barrier, 1u);
     ticket = __shfl(ticket, 0);
@@ -530,7 +559,7 @@ __global__ void __launch_bounds__(64) photon_small_kernel(const WalkParams W, co
     acc.size += (unsigned)(grand & 0xFFFFFFFFull);
     acc.contrib += (unsigned)(grand >> 32);
     acc.error = __hip_atomic_load(W.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (acc.done && !acc.error) {
+    if (acc.done && !acc.error && !direct) {
         const unsigned* src = reinterpret_cast<const unsigned*>(K.d_out);
         unsigned* dst = reinterpret_cast<unsigned*>(K.h_out);
         const unsigned n_words = K.max_vpl * 24u;
@@ -555,6 +584,12 @@ __global__ void __launch_bounds__(64) photon_small_kernel(const WalkParams W, co
         *K.h_acc = acc;
         *W.error = 0u;
     }
+    STAMP();
+    // the host waits for this word rather than for the launch to retire: everything the wave wrote to host memory is
+    // out (system scope) before the word is
+    __threadfence_system();
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0u) __hip_atomic_store(K.h_flag, K.token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 }  // namespace
@@ -565,6 +600,9 @@ extern "C" int gigl_photon_trace_batch(const gigl_scene* s, const gigl_fog* fog,
                                        int max_vpl_count, uint64_t seed, uint32_t paths_per_batch, void* vpls_out,
                                        int* n_vpls_out, uint32_t* n_paths_out) {
     (void)shoot_dir;   // PhotonTracer.cpp:86-88 builds a frame from it that the walk never uses
+#if GIGL_PHOTON_STAMPS
+    const auto t_entry = std::chrono::steady_clock::now();
+#endif
     if (n_vpls_out) *n_vpls_out = 0;
     if (n_paths_out) *n_paths_out = 0;
     if (!s || !materials || !ppl_pos || !ppl_intens || !vpls_out || !n_vpls_out)
@@ -651,7 +689,8 @@ extern "C" int gigl_photon_trace_batch(const gigl_scene* s, const gigl_fog* fog,
         if (small) {
             constexpr size_t h_bytes = (size_t)kSmallMaxVpls * sizeof(VplRec) + 256;
             if (!ms->photon_h) {
-                HIP_TRY(hipHostMalloc(&ms->photon_h, h_bytes, hipHostMallocMapped));
+                // coherent: the host reads the set as soon as the kernel's flag says it is complete, not at the end of the launch
+                HIP_TRY(hipHostMalloc(&ms->photon_h, h_bytes, hipHostMallocMapped | hipHostMallocCoherent));
                 HIP_TRY(hipHostGetDevicePointer(&ms->photon_h_dev, ms->photon_h, 0));
             }
             TraceParams Q = {};
@@ -681,20 +720,85 @@ extern "C" int gigl_photon_trace_batch(const gigl_scene* s, const gigl_fog* fog,
                 ms->photon_small_at = ws + o_small;
                 ms->photon_epoch = 0u;
             }
-            K.lanes = P <= 1024u ? 8u : (P <= 2048u ? 16u : 32u);   // at most 128 waves per launch
+            // A launch walks what the set is expected to need and a quarter more (the workspace stays sized for P): a
+            // set of the reference's size needs about 3 paths per record, so 640 paths in 80 waves rather than 1,024
+            // in 128 — the barrier waits for the slowest wave of fewer.  The estimate follows the sets made so far.
+            const unsigned Ps = std::min<unsigned>(P, std::max<unsigned>(256u,
+                (unsigned)(1.25f * ms->photon_rate * (float)max_vpl_count + 127.0f) & ~127u));
+            K.lanes = Ps <= 512u ? 4u : (Ps <= 1024u ? 8u : (Ps <= 2048u ? 16u : 32u));   // at most 128 waves per launch
+#if GIGL_PHOTON_STAMPS
+            static unsigned long long* h_stamps = nullptr;
+            static unsigned long long* d_stamps = nullptr;
+            if (!h_stamps) {
+                HIP_TRY(hipHostMalloc((void**)&h_stamps, 128 * 16 * 8, hipHostMallocMapped | hipHostMallocCoherent));
+                HIP_TRY(hipHostGetDevicePointer((void**)&d_stamps, h_stamps, 0));
+            }
+            std::memset(h_stamps, 0, 128 * 16 * 8);
+            K.stamps = d_stamps;
+#endif
             auto kern = s->triples ? photon_small_kernel<true> : photon_small_kernel<false>;
             const Acc* h_acc = (const Acc*)((char*)ms->photon_h + (size_t)kSmallMaxVpls * sizeof(VplRec));
+            volatile unsigned* h_flag = (volatile unsigned*)((char*)ms->photon_h + (size_t)kSmallMaxVpls * sizeof(VplRec) + 128);
+            K.h_flag = (unsigned*)((char*)ms->photon_h_dev + (size_t)kSmallMaxVpls * sizeof(VplRec) + 128);
             uint64_t first = 0;
             while (first < path_limit) {
-                const unsigned nb = (unsigned)std::min<uint64_t>(P, path_limit - first);
+                const unsigned nb = (unsigned)std::min<uint64_t>(Ps, path_limit - first);
                 const unsigned grid = (nb + K.lanes - 1u) / K.lanes;
                 W.first = (unsigned)first; W.n = nb;
                 Q.spill_stride = grid * 64u;
                 K.epoch = ms->photon_epoch;
                 ms->photon_epoch += 2u * grid;
+                K.token = ms->photon_epoch | 0x80000000u;   // never 0, new with every launch
+                *h_flag = 0u;
+#if GIGL_PHOTON_STAMPS
+                const auto tq0 = std::chrono::steady_clock::now();
+#endif
                 hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, st, W, Q, K);
                 hipError_t le = hipGetLastError();
-                if (le == hipSuccess) le = hipStreamSynchronize(st);
+#if GIGL_PHOTON_STAMPS
+                const auto tq1 = std::chrono::steady_clock::now();
+#endif
+                // The last wave raises the flag when the set and the totals are in host memory: the call returns then,
+                // some 20 us before the runtime would report the launch retired.  Every few thousand polls the stream is
+                // asked whether it failed or finished without the flag (a fault, a barrier that gave up).
+                if (le == hipSuccess) {
+                    for (unsigned spins = 1u;; ++spins) {
+                        if (__atomic_load_n((const unsigned*)h_flag, __ATOMIC_ACQUIRE) == K.token) break;
+                        if ((spins & 4095u) == 0u) {
+                            const hipError_t q = hipStreamQuery(st);
+                            if (q != hipErrorNotReady) {   // retired (or failed): whatever it wrote is there now
+                                le = q;
+                                break;
+                            }
+                        }
+                    }
+                }
+#if GIGL_PHOTON_STAMPS
+                if (getenv("GIGL_PHOTON_TIMING")) {
+                    (void)hipStreamSynchronize(st);
+                    // per stamp: latest wave, relative to the earliest start; names of the intervals
+                    static const char* nm[] = {"start", "path_start", "walk1", "bounce1", "walk2", "bounce2", "walk3", "bounce3",
+                                               "scan", "barrier", "place", "last wave: host copy"};
+                    unsigned long long t0 = ~0ull;
+                    for (unsigned w = 0; w < grid; ++w) t0 = std::min(t0, h_stamps[w * 16]);
+                    fprintf(stderr, "[stamps] %u waves;", grid);
+                    for (unsigned k = 0; k < 12; ++k) {
+                        unsigned long long mx = 0; double mean = 0; unsigned cnt = 0;
+                        for (unsigned w = 0; w < grid; ++w) if (h_stamps[w * 16 + k]) { mx = std::max(mx, h_stamps[w * 16 + k]); mean += (double)(h_stamps[w * 16 + k] - t0); ++cnt; }
+                        if (cnt) fprintf(stderr, " %s %.1f/%.1f", nm[k], mean / cnt * 0.01, (double)(mx - t0) * 0.01);
+                    }
+                    fprintf(stderr, " (us since the first wave started: mean/latest over waves)\n");
+                }
+#endif
+#if GIGL_PHOTON_STAMPS
+                if (getenv("GIGL_PHOTON_TIMING")) {
+                    const auto tq2 = std::chrono::steady_clock::now();
+                    fprintf(stderr, "[photon_small] entry->launch %.1f us, launch call %.1f us, wait %.1f us\n",
+                            std::chrono::duration<double, std::micro>(tq0 - t_entry).count(),
+                            std::chrono::duration<double, std::micro>(tq1 - tq0).count(),
+                            std::chrono::duration<double, std::micro>(tq2 - tq1).count());
+                }
+#endif
                 if (le != hipSuccess) {
                     ms->photon_small_at = nullptr;   // the counter is no longer where the host thinks it is
                     return fail(GIGL_ERR_HIP, std::string("photon_small_kernel: ") + hipGetErrorString(le));
@@ -714,6 +818,7 @@ extern "C" int gigl_photon_trace_batch(const gigl_scene* s, const gigl_fog* fog,
                 return GIGL_OK;
             }
             std::memcpy(vpls_out, ms->photon_h, (size_t)max_vpl_count * sizeof(VplRec));
+            ms->photon_rate = std::max(0.5f, 0.5f * ms->photon_rate + 0.5f * (float)acc.n_paths / (float)max_vpl_count);
             *n_vpls_out = max_vpl_count;
             if (n_paths_out) *n_paths_out = acc.n_paths;
             return GIGL_OK;

@@ -236,8 +236,12 @@ __device__ __forceinline__ void spill_load(const uint4* p, unsigned& a, unsigned
 constexpr unsigned kStatsTimeline = 16u;
 constexpr unsigned kStatsWords = kStatsTimeline + 3u * 1024u;
 
-template <bool TRIPLES, bool ANY, int GEN, int STACK_N, int BLOCK, bool STATS = false, bool XCHG = false>
-__device__ __forceinline__ void trace_body(const TraceParams& P) {
+// SOLO (photon_small_kernel): the workgroup is one wave whose whole batch is rays [0, P.n), P.n <= 64: no work counter
+// (two atomic round trips saved per call), and a caller that calls again in the same kernel says that the epsilon
+// table in LDS is already filled.
+template <bool TRIPLES, bool ANY, int GEN, int STACK_N, int BLOCK, bool STATS = false, bool XCHG = false, bool SOLO = false>
+__device__ __forceinline__ void trace_body(const TraceParams& P, bool eps_ready = false) {
+    static_assert(!SOLO || BLOCK == 64, "a solo batch belongs to a one-wave workgroup");
     static_assert(!XCHG || (TRIPLES && !ANY && GEN == 0 && BLOCK == 256), "the exchange is built for one configuration");
     // stack entry = (t_split, the far child's two words): the far child is in registers when the
     // entry is pushed, so a pop costs no global load (pairs) or at most the record's (triples)
@@ -249,8 +253,10 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
     __shared__ unsigned s_xalive[XCHG ? 4 : 1];     // XCHG: per wave, whether it still has rays or may get some
     const unsigned tid = threadIdx.x;
     const unsigned lane = tid & 63u;
-    for (int i = (int)tid; i < kEpsTable; i += BLOCK) s_eps[i] = eps_from_exp(i - kEpsBias + 1);
-    __syncthreads();
+    if (!(SOLO && eps_ready)) {
+        for (int i = (int)tid; i < kEpsTable; i += BLOCK) s_eps[i] = eps_from_exp(i - kEpsBias + 1);
+        __syncthreads();
+    }
 #if GIGL_EPS_ALU
     // For frexp exponents in [-31, 29] (|t| in [2^-32, 2^29), and 0/inf/NaN, whose exponent reads 0) the
     // reference's value is 2^(e - 23) whichever branch of RTBase.h:24-28 it takes: assembled in two
@@ -431,9 +437,15 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
                     const unsigned g = (rem / P.guided) & ~63u;
                     take_n = g < 64u ? 64u : (g < P.chunk ? g : P.chunk);
                 }
-                if (lane == 0) base = atomicAdd(P.counter, take_n);
-                base = __builtin_amdgcn_readfirstlane(base);
-                last_base = base;
+                if constexpr (SOLO) {   // the first request is the whole batch, the second finds nothing
+                    base = last_base;
+                    take_n = P.n;
+                    last_base = P.n;
+                } else {
+                    if (lane == 0) base = atomicAdd(P.counter, take_n);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    last_base = base;
+                }
                 pool_next = base < P.n ? base : P.n;
                 pool_end = (P.n - pool_next) < take_n ? P.n : pool_next + take_n;
                 if (pool_next == pool_end) pool_empty = true;
