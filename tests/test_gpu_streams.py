@@ -153,3 +153,29 @@ def test_pool_is_trimmed_on_request_and_with_the_last_scene(cornell):
     with pytest.raises(rt.GiglError):
         rt.trim_pool(1000)
     g.close()
+
+
+def test_instrumented_build_counts_and_timeline(s64):
+    """Option `stats`: the instrumented kernel returns the same records and its counters add up — every ray is
+    handed to a lane exactly once; the timeline (every 16th wave) sees about a sixteenth of them, in order of time."""
+    import torch
+    g, n = s64["gpu"], s64["n"]
+    out = torch.zeros((n, 4), dtype=torch.int32, device="cuda")
+    rt.set_option("stats", 1)
+    try:
+        g.trace_closest_device(s64["d_o"].data_ptr(), s64["d_d"].data_ptr(), n, out.data_ptr(),
+                               torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        st = rt.debug_last_stats()
+        tl = rt.debug_last_timeline()
+    finally:
+        rt.set_option("stats", 0)
+    assert np.array_equal(out.cpu().numpy(), s64["want"])
+    assert st["refill_lanes"] >= n and st["rounds"] > 0 and st["waves"] > 0
+    assert st["t_lane_steps"] <= 64 * st["t_iters"] and st["l_lane_rounds"] <= 64 * st["l_rounds"]
+    assert tl.shape == (3, 1024)
+    started, rounds, lanes = (int(tl[k].sum()) for k in range(3))
+    assert n // 32 < started < n // 8, (started, n)            # a sixteenth of the waves, give or take
+    assert rounds > 0 and lanes <= 64 * rounds
+    used = np.nonzero(tl[1])[0]
+    assert used[0] == 0 and used[-1] < 1023                    # starts in the first bucket, ends long before the wrap
