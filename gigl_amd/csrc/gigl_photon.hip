@@ -19,6 +19,7 @@
 
 #include <chrono>
 #include "gigl_trace_body.h"   // the traversal body: photon_small_kernel walks the tree itself
+#include "gigl_walk_lean.h"    // ... in this lean form when the scene is in triple records
 
 using namespace gd;
 
@@ -381,9 +382,9 @@ __global__ void __launch_bounds__(256) vpl_normalize_kernel(VplRec* out, unsigne
 // 0.21 ms for the reference's own 150-VPL set.  For blocks of up to kSmallMaxPaths paths one launch does
 // everything: a workgroup is ONE wave that walks 4 to 32 paths on its first lanes (the fewer paths a wave holds,
 // the fewer rounds its divergent loops take, and up to 128 such waves spread over the chip; none of them waits
-// for another during the walk); per bounce the wave walks the tree itself (trace_body in its SOLO form: the same
-// traversal code as every other query, its batch the wave's own rays, no work counter), then every lane advances
-// its path.  The ordered gather: the waves publish their record counts and meet at one barrier in global memory;
+// for another during the walk); per bounce the wave walks the tree itself (triple records: walk_lean, one ray per
+// lane in one lean loop, gigl_walk_lean.h; the other layouts: trace_body in its SOLO form, its batch the wave's own
+// rays, no work counter), then every lane advances its path.  The ordered gather: the waves publish their record counts and meet at one barrier in global memory;
 // behind it every wave knows where its records go and what 1 / n_paths is (LightArray::normalizeIntensity,
 // LightArray.hpp:46-66), and writes its own records, scaled, straight into the page-locked host set; the last wave
 // to check out adds the totals and raises a flag in host memory, which the host call polls instead of waiting for
@@ -472,7 +473,10 @@ __global__ void __launch_bounds__(64) photon_small_kernel(const WalkParams W, co
     STAMP();
     for (int b = 1; b <= kGiBounces; ++b) {
         phase_fence();
-        trace_body<TRIPLES, false, 0, 8, 64, false, false, true>(Q, b > 1);
+        // triple records (the default layout): every lane walks its own ray in one lean loop; the other layouts go
+        // through the shared body in its one-wave form
+        if constexpr (TRIPLES) walk_lean<64>(Q, lane < Q.n, lane);
+        else trace_body<TRIPLES, false, 0, 8, 64, false, false, true>(Q, b > 1);
         phase_fence();
         STAMP();
         if (mine_path) path_bounce(W, i, b == kGiBounces ? 1 : 0);

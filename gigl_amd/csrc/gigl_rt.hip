@@ -970,7 +970,7 @@ int gigl_scene_create_from_device_blob(const gigl_scene_blob* desc, const void* 
     // table of 64-byte records for n_tris triangles in front of the leaf blocks, layouts 0..2
     if (desc->nb_nodes < 16 || desc->nb_nodes % 8 || desc->layout > 2u || (desc->triples != 0u) != (desc->layout == 2u) ||
         desc->nb_tris < (uint64_t)desc->n_tris * 4 * kTriStride * 4 || (uint64_t)desc->blocks_off8 * 8 > desc->nb_tris ||
-        desc->stats.actual_depth < 0 || desc->stats.actual_depth > 64)
+        desc->stats.actual_depth < 0 || desc->stats.actual_depth > 32)   // the traversal stacks hold 32 entries
         return fail(GIGL_ERR_INVALID, "inconsistent scene blob header");
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
