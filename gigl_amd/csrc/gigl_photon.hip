@@ -596,7 +596,32 @@ __global__ void __launch_bounds__(64) photon_small_kernel(const WalkParams W, co
     if (lane == 0u) __hip_atomic_store(K.h_flag, K.token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// walk_lean over an explicit ray batch, one ray per lane, 64 per workgroup: the cross-check of the lean walk against
+// the shipped kernel on batches of any size (tests), and the measure of what a lone ray costs in either form
+__global__ void __launch_bounds__(64) lean_trace_kernel(const TraceParams P) {
+    const unsigned i = blockIdx.x * 64u + threadIdx.x;
+    walk_lean<64>(P, i < P.n, i);
+}
+
 }  // namespace
+
+extern "C" int gigl_debug_trace_closest_lean_device(const gigl_scene* s, const void* o_tmin, const void* d_tmax, uint64_t n,
+                                                    gigl_hit* hits, void* stream) {
+    if (!s || ((!o_tmin || !d_tmax || !hits) && n)) return fail(GIGL_ERR_INVALID, "NULL argument");
+    if (s->device == GIGL_DEVICE_NONE) return fail(GIGL_ERR_NO_DEVICE, "host-only scene: no device to trace on");
+    if (!s->triples) return fail(GIGL_ERR_INVALID, "the lean walk reads triple records (layout 2)");
+    if (n > kMaxRays) return fail(GIGL_ERR_TOO_LARGE, "at most 0xF0000000 rays per call");
+    if (n == 0) return GIGL_OK;
+    DeviceGuard g(s->device);
+    TraceParams P = {};
+    scene_trace_params(s, P);
+    P.o_tmin = (const float4*)o_tmin; P.d_tmax = (const float4*)d_tmax;
+    P.hits = (uint4*)hits;
+    P.n = (unsigned)n;
+    hipLaunchKernelGGL(lean_trace_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream, P);
+    HIP_TRY(hipGetLastError());
+    return GIGL_OK;
+}
 
 extern "C" int gigl_photon_trace_batch(const gigl_scene* s, const gigl_fog* fog, const float* materials, uint32_t n_mat,
                                        float abs_k, float sca_k, float maj_ext_k, int fog_enabled,

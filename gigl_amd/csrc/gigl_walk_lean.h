@@ -16,7 +16,7 @@ using namespace gd;
 // 32-entry stack in LDS (no spill area) and the epsilon assembled in registers.  Per ray the sequence of reference
 // operations (KdTree.hpp:266-347), the order of the triangle tests and every expression are trace_body's, so the
 // records are the same bit for bit (tests/test_gpu_vpl_batch.py compares both walks with the oracle's).
-// Outputs as trace_body's finish() with P.ranges / P.hit_tri set.  Call with the whole wave; `active` lanes hold a ray.
+// Outputs as trace_body's finish() (P.ranges / P.hit_tri optional).  Call with the whole wave; `active` lanes hold a ray.
 template <int BLOCK>
 __device__ __forceinline__ void walk_lean(const TraceParams& P, bool active, unsigned ray_idx) {
     constexpr int kDepth = 32;
@@ -137,8 +137,8 @@ __device__ __forceinline__ void walk_lean(const TraceParams& P, bool active, uns
     }
     P.hits[ray_idx] = hit ? make_uint4(best_id, __float_as_uint(best_t), __float_as_uint(best_u), __float_as_uint(best_v))
                           : make_uint4(kMiss, __float_as_uint(FLT_MAX), 0u, 0u);
-    P.ranges[ray_idx] = make_float2(r.tmin, r.tmax);
-    if (hit) {
+    if (P.ranges) P.ranges[ray_idx] = make_float2(r.tmin, r.tmax);
+    if (hit && P.hit_tri) {
         const float4* t = tris + kTriStride * (size_t)best_id;
         P.hit_tri[3 * ray_idx] = t[0]; P.hit_tri[3 * ray_idx + 1] = t[1]; P.hit_tri[3 * ray_idx + 2] = t[2];
     }

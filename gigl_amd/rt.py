@@ -25,7 +25,7 @@ SYMBOLS = [
     "gigl_trace_any_device", "gigl_trace_any", "gigl_trace_one", "gigl_camera_setup",
     "gigl_gen_primary_rays_device", "gigl_trace_primary_device", "gigl_shadow_batch_device", "gigl_fog_create",
     "gigl_fog_destroy", "gigl_transmittance_device", "gigl_sample_density", "gigl_debug_rescaled_eps",
-    "gigl_set_option", "gigl_debug_last_stats", "gigl_debug_last_timeline", "gigl_compute_pi_density_device", "gigl_shade_surface_device",
+    "gigl_set_option", "gigl_debug_last_stats", "gigl_debug_last_timeline", "gigl_debug_trace_closest_lean_device", "gigl_compute_pi_density_device", "gigl_shade_surface_device",
     "gigl_tonemap_device", "gigl_volume_samples_device", "gigl_shadow_points_device", "gigl_shade_volume_device",
     "gigl_depth_buffer_device", "gigl_combine_device", "gigl_debug_check_layout", "gigl_scene_layout",
     "gigl_trace_closest_noalloc_device", "gigl_multi_create", "gigl_multi_destroy", "gigl_multi_device_count",
@@ -124,6 +124,7 @@ def lib():
         L.gigl_set_option.argtypes = [C.c_char_p, i]
         L.gigl_debug_last_stats.argtypes = [vp]
         L.gigl_debug_last_timeline.argtypes = [vp]
+        L.gigl_debug_trace_closest_lean_device.argtypes = [vp, vp, vp, u64, vp, vp]
         L.gigl_debug_check_layout.argtypes = [vp, i, i, vp]
         L.gigl_compute_pi_density_device.argtypes = [vp, vp, vp, i, i, vp, vp]
         L.gigl_shade_surface_device.argtypes = [vp, vp, vp, vp, vp, vp, u64, vp, u32, vp, vp, vp, vp, vp, vp, vp, vp]
@@ -359,6 +360,10 @@ class Scene:
     # ---- device-pointer calls (ints from torch.Tensor.data_ptr()) ----
     def trace_closest_device(self, o_ptr, d_ptr, n, hits_ptr, stream=0):
         _check(lib().gigl_trace_closest_device(self.h, o_ptr, d_ptr, n, hits_ptr, stream))
+
+    def debug_trace_closest_lean_device(self, o_ptr, d_ptr, n, hits_ptr, stream=0):
+        """trace_closest_device through the lean one-ray-per-lane walk (diagnostic; triple-record scenes)."""
+        _check(lib().gigl_debug_trace_closest_lean_device(self.h, o_ptr, d_ptr, n, hits_ptr, stream))
 
     def trace_closest_noalloc_device(self, o_ptr, d_ptr, n, hits_ptr, stream=0):
         """trace_closest_device without any allocation (static device scratch; see include/gigl_rt.h)."""

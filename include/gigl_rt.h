@@ -371,6 +371,13 @@ int gigl_debug_check_layout(const gigl_scene* s, int layout, int treelet_levels,
  * 100 MHz real-time counter: ~(earliest wave start), latest wave end, sum of wave ends, waves. */
 int gigl_debug_last_stats(uint64_t out[12]);
 
+/* Closest-hit over an explicit device ray batch through the lean one-ray-per-lane walk that small VPL sets use
+ * (gigl_walk_lean.h; scenes in triple records only), same arguments and records as gigl_trace_closest_device.
+ * Diagnostic: the cross-check of that walk against the shipped kernel on batches of any size, and the measure of
+ * what a lone ray costs in either form.  No counterpart in the reference. */
+int gigl_debug_trace_closest_lean_device(const gigl_scene* s, const void* o_tmin, const void* d_tmax, uint64_t n,
+                                         gigl_hit* hits, void* stream);
+
 /* The same launch over time: three histograms of 1024 buckets of 81.92 us of the 100 MHz real-time counter,
  * fed by every 16th wave (bucket = (t >> 13) & 1023, so they wrap after 84 ms; gigl_debug_last_stats' earliest start says where
  * the launch begins): rays handed to lanes, rounds of all waves, lanes holding a ray summed over those

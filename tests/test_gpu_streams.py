@@ -179,3 +179,15 @@ def test_instrumented_build_counts_and_timeline(s64):
     assert rounds > 0 and lanes <= 64 * rounds
     used = np.nonzero(tl[1])[0]
     assert used[0] == 0 and used[-1] < 1023                    # starts in the first bucket, ends long before the wrap
+
+
+def test_lean_walk_equals_the_shipped_kernel(s64):
+    """The one-ray-per-lane walk of small VPL sets (gigl_walk_lean.h) over the module's 6.3 M rays: every record
+    equal to the shipped kernel's (which the fixture pinned to the oracle)."""
+    import torch
+    g, n = s64["gpu"], s64["n"]
+    out = torch.zeros((n, 4), dtype=torch.int32, device="cuda")
+    g.debug_trace_closest_lean_device(s64["d_o"].data_ptr(), s64["d_d"].data_ptr(), n, out.data_ptr(),
+                                      torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), s64["want"])

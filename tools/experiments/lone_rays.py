@@ -27,5 +27,23 @@ for name, sel in (("the longest ray alone", idx[:1]), ("the 64 longest (one wave
         e0.record(); scene.trace_closest_device(o.data_ptr(), d.data_ptr(), len(sel), hits.data_ptr(), sh); e1.record()
         torch.cuda.synchronize(); best = min(best, e0.elapsed_time(e1))
     k = np.isin(idx, sel)
-    print("%-34s %7.3f ms; longest %d nodes + %d tests -> %.3f us per node of the longest ray; all: %d nodes" % (
-        name, best, nodes[k].max(), tris[k][np.argmax(nodes[k])], best * 1e3 / nodes[k].max(), nodes[k].sum()), flush=True)
+    lean = 1e9
+    hits2 = torch.empty_like(hits)
+    for rep in range(5):
+        e0.record(); scene.debug_trace_closest_lean_device(o.data_ptr(), d.data_ptr(), len(sel), hits2.data_ptr(), sh); e1.record()
+        torch.cuda.synchronize(); lean = min(lean, e0.elapsed_time(e1))
+    same = bool(torch.equal(hits, hits2))
+    print("%-34s %7.3f ms; longest %d nodes + %d tests -> %.3f us per node of the longest ray; all: %d nodes; lean walk %.3f ms, records %s" % (
+        name, best, nodes[k].max(), tris[k][np.argmax(nodes[k])], best * 1e3 / nodes[k].max(), nodes[k].sum(), lean,
+        "equal" if same else "DIFFER"), flush=True)
+
+# the whole 2^21-ray batch through both kernels
+o = torch.from_numpy(ro).to(dev); d = torch.from_numpy(rd).to(dev)
+h1 = torch.empty((len(ro), 4), dtype=torch.int32, device=dev); h2 = torch.empty_like(h1)
+e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e2 = torch.cuda.Event(enable_timing=True)
+for rep in range(2):
+    e0.record(); scene.trace_closest_device(o.data_ptr(), d.data_ptr(), len(ro), h1.data_ptr(), sh); e1.record()
+    scene.debug_trace_closest_lean_device(o.data_ptr(), d.data_ptr(), len(ro), h2.data_ptr(), sh); e2.record()
+    torch.cuda.synchronize()
+print("all 2^21 rays: shipped kernel %.3f ms, lean one-ray-per-lane kernel %.3f ms, records %s" % (
+    e0.elapsed_time(e1), e1.elapsed_time(e2), "equal" if torch.equal(h1, h2) else "DIFFER"), flush=True)
