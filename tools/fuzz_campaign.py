@@ -57,6 +57,13 @@ for seed in range(first, first + n_scenes):
                 rep = rt.Scene.from_device_blob(desc, ptrs[0], ptrs[1], ptrs[2], device=0)
                 ok = ok and np.array_equal(rep.trace(ro, rd).view(np.uint32), got.view(np.uint32))
                 rep.close()
+                # the lean one-ray-per-lane walk of small VPL sets (gigl_walk_lean.h) over the same rays
+                import torch
+                d_o, d_d = torch.from_numpy(ro).cuda(), torch.from_numpy(rd).cuda()
+                h = torch.zeros((len(ro), 4), dtype=torch.int32, device="cuda")
+                gpu.debug_trace_closest_lean_device(d_o.data_ptr(), d_d.data_ptr(), len(ro), h.data_ptr(), 0)
+                torch.cuda.synchronize()
+                ok = ok and np.array_equal(h.cpu().numpy().view(np.uint32).reshape(-1), got.view(np.uint32).reshape(-1))
             if not ok:
                 bad += 1
                 print("MISMATCH seed %d layout %d stack %d tris %d %s %r" % (seed, layout, stack_lds, n_tris, flavour, params),
