@@ -380,20 +380,21 @@ __global__ void __launch_bounds__(256) vpl_normalize_kernel(VplRec* out, unsigne
 // ---- a whole small set in one launch ---------------------------------------------------------------
 // The batched route above is a chain of a dozen dependent launches and a read-back per block of paths:
 // 0.21 ms for the reference's own 150-VPL set.  For blocks of up to kSmallMaxPaths paths one launch does
-// everything: a workgroup is ONE wave that walks 4 to 32 paths on its first lanes (the fewer paths a wave holds,
-// the fewer rounds its divergent loops take, and up to 128 such waves spread over the chip; none of them waits
-// for another during the walk); per bounce the wave walks the tree itself (triple records: walk_lean, one ray per
-// lane in one lean loop, gigl_walk_lean.h; the other layouts: trace_body in its SOLO form, its batch the wave's own
-// rays, no work counter), then every lane advances its path.  The ordered gather: the waves publish their record counts and meet at one barrier in global memory;
-// behind it every wave knows where its records go and what 1 / n_paths is (LightArray::normalizeIntensity,
-// LightArray.hpp:46-66), and writes its own records, scaled, straight into the page-locked host set; the last wave
-// to check out adds the totals and raises a flag in host memory, which the host call polls instead of waiting for
-// the launch to retire.  One launch, no copy.  Same arithmetic, same order of records: byte-identical to the
-// batched route.  What a set costs is then the slowest wave's dependent chain (GIGL_PHOTON_STAMPS=1 builds stamp it:
-// three tree walks of 10-17 us each — a lone wave issues an instruction every 8-13 cycles — three path steps of
-// 6-8 us, 5-10 us behind the barrier for the placement), 75-85 us in all against 35 us for the average wave.
-constexpr unsigned kSmallMaxPaths = 4096;   // 128 waves: their totals are scanned by one wave, two per lane
-constexpr unsigned kSmallMaxVpls = 1024;    // records the page-locked staging holds
+// everything on the device: a workgroup is ONE wave that walks 1 to 16 paths on its first lanes (a wave takes, at
+// every phase, as long as the longest of its paths; a few hundred such waves spread over the chip and none of them
+// waits for another); per bounce the wave walks the tree itself (triple records: walk_lean, one ray per lane in one
+// lean loop, gigl_walk_lean.h; the other layouts: trace_body in its SOLO form, its batch the wave's own rays, no work
+// counter), then every lane advances its path, writing the records it makes straight into page-locked host memory.
+// A path that holds records finally writes how many, the wave checks in and leaves; the last wave to check in raises
+// a flag in host memory, which the host call polls instead of waiting for the launch to retire.  The ordered gather
+// (where every record goes, which path completes the set and hence 1 / n_paths, the renumbering of the contributing
+// paths: LightArray::normalizeIntensity, LightArray.hpp:46-66) is then a walk over a few hundred counts and a copy
+// of the set's records on the host.  One launch, no device-to-host copy.  Same arithmetic, same order of records:
+// byte-identical to the batched route.  What a set costs is the dependent chain of its slowest path
+// (GIGL_PHOTON_STAMPS=1 builds stamp it: three tree walks and three path steps, some 8,000 instructions of a lone
+// wave at one every 8-13 cycles: 50-57 us, against 20 us for the average wave) plus launch and flag latency.
+constexpr unsigned kSmallMaxPaths = 4096;   // paths per launch: the page-locked slots hold three records for each
+constexpr unsigned kSmallMaxVpls = 1024;    // largest set the one-launch route takes (4 x 1,024 paths per launch)
 
 // the phases of a wave exchange their data through global memory: the fence completes the stores before the loads
 // of the next phase are issued
@@ -402,50 +403,18 @@ __device__ __forceinline__ void phase_fence() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __builtin_amdgcn_wave_barrier();
 }
-__device__ __forceinline__ unsigned long long wave_inclusive_scan(unsigned long long v, unsigned lane) {
-#pragma unroll
-    for (unsigned off = 1; off < 64u; off <<= 1) {
-        const unsigned long long t = __shfl_up(v, off);
-        if (lane >= off) v += t;
-    }
-    return v;
-}
-
-// Every wave of the launch arrives, then waits until the counter has reached `target` (the counter only grows: the
-// host hands every launch the value it starts from).  Returns true if the wait gave up: a wave never spins for ever.
-__device__ __forceinline__ bool grid_barrier(unsigned* ctr, unsigned target, unsigned lane) {
-    __threadfence();   // what this wave wrote is out before it arrives
-    bool gave_up = false;
-    if (lane == 0u) {
-        atomicAdd(ctr, 1u);
-        unsigned spins = 0u;
-        while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-            if (++spins > (1u << 22)) { gave_up = true; break; }   // seconds: the other waves never came
-            __builtin_amdgcn_s_sleep(1);
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    __threadfence();   // and what the others wrote is seen after it
-    return gave_up;
-}
-
 struct SmallParams {
-    unsigned max_vpl;
-    VplRec* d_out;                   // kept records (device), unscaled
-    VplRec* h_out;                   // page-locked host memory as the device sees it: the finished set
-    Acc* d_acc;                      // running totals over the launches of one call
-    Acc* h_acc;                      // the same, for the host
-    unsigned long long* wg_totals;   // per wave of the launch: (records, contributing paths)
-    unsigned* barrier;               // arrivals at the grid barriers; only grows
+    unsigned* h_cnt;                 // page-locked host memory as the device sees it: per path of the launch, the records
+                                     // it holds (the host zeroes it; only paths that hold any write theirs)
+    unsigned* h_err;                 // ... the error word of the launch (path_bounce's), written by the last wave
+    unsigned* h_flag;                // ... and the word the last wave sets to `token` once every wave has checked in
+    unsigned token;
+    unsigned* arrivals;              // device: waves that have checked in; only grows
     unsigned epoch;                  // its value when this launch starts
-    unsigned long long* wg_masks;    // per wave: bit 0 and bit 1 of the record count of each of its paths
-    unsigned* counters;              // two words per wave: its traversal work counter
-    unsigned lanes;                  // paths per wave: 8, 16, 32 (or 64)
+    unsigned lanes;                  // paths per wave: 1, 2, 4 ... 32
 #if GIGL_PHOTON_STAMPS
     unsigned long long* stamps;      // 16 real-time stamps per wave (diagnostic build)
 #endif
-    unsigned* h_flag;                // page-locked host word: the last wave writes `token` once the set and the totals are out
-    unsigned token;
 };
 
 template <bool TRIPLES>
@@ -468,7 +437,11 @@ __global__ void __launch_bounds__(64) photon_small_kernel(const WalkParams W, co
     Q.o_tmin = P.o_tmin + g * L; Q.d_tmax = P.d_tmax + g * L;
     Q.hits = P.hits + g * L; Q.ranges = P.ranges + g * L; Q.hit_tri = P.hit_tri + 3u * g * L;
     Q.n = nb - g * L < L ? nb - g * L : L;
-    Q.counter = K.counters + 2u * g;
+    Q.counter = nullptr;   // SOLO: no work counter
+    // trace_body addresses its spill column by workgroup * 64 + lane; only the first L lanes of a wave ever hold a
+    // ray, so the columns of consecutive waves are packed L apart (the host sizes the area for the paths, not for
+    // 64 lanes per wave)
+    Q.spill = P.spill - (size_t)g * (64u - L);
     if (mine_path) path_start(W, i);
     STAMP();
     for (int b = 1; b <= kGiBounces; ++b) {
@@ -482,118 +455,34 @@ __global__ void __launch_bounds__(64) photon_small_kernel(const WalkParams W, co
         if (mine_path) path_bounce(W, i, b == kGiBounces ? 1 : 0);
         STAMP();
     }
-    // ---- the ordered gather (vpl_gather_kernel's), every wave placing its own records ----
-    // The waves of a launch (at most 128 single-wave workgroups: all resident at once) meet once at a barrier in
-    // global memory, having published how many records each holds, and how many each of its paths holds (two bit
-    // masks per wave).  Behind it every wave knows where its own records go, which path supplies record number
-    // max_vpl — the last path the serial loop counts — and with it 1 / n_paths.
-    const unsigned cnt = mine_path ? W.state[i].n_vpl : 0u;   // this lane's own store; at most kGiBounces = 3
-    const unsigned long long mine = (unsigned long long)cnt | ((unsigned long long)(cnt ? 1u : 0u) << 32);
-    const unsigned long long incl = wave_inclusive_scan(mine, lane);
-    const unsigned long long b0 = __ballot((cnt & 1u) != 0u), b1 = __ballot((cnt & 2u) != 0u);
-    if (lane == 63u) {
-        K.wg_totals[g] = incl;
-        K.wg_masks[2u * g] = b0;
-        K.wg_masks[2u * g + 1u] = b1;
-    }
+    // ---- the ordered gather (vpl_gather_kernel's) is the host's ----
+    // W.slots is page-locked host memory here: the records went out as path_bounce made them.  A path that holds
+    // any now says how many; then the wave checks in and leaves — nobody waits.  The wave that checks in last
+    // raises the flag the host call polls, and the host lays the set out: it walks the paths' counts in order, which
+    // gives every record its place, the path that supplies record number max_vpl (the last one the serial loop
+    // counts, hence 1 / n_paths) and the renumbering of the contributing paths (LightArray::normalizeIntensity,
+    // LightArray.hpp:46-66) — a few hundred words and some 150 records, microseconds of one core, where a lone wave
+    // took 10-15 us over the same job (and an earlier form, a barrier in global memory behind which every wave placed
+    // its own records, had the waves that were done early polling: a few hundred pollers slowed the ones still
+    // walking down several times).
+    const unsigned cnt = mine_path ? W.state[i].n_vpl : 0u;   // at most kGiBounces = 3
+    if (cnt) K.h_cnt[g * L + lane] = cnt;
     STAMP();
-    const bool timed_out = grid_barrier(K.barrier, K.epoch + gridDim.x, lane);
-    STAMP();
-    const unsigned n_w = gridDim.x;
-    const unsigned long long t0 = lane < n_w ? __hip_atomic_load(K.wg_totals + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-    const unsigned long long t1 = lane + 64u < n_w ? __hip_atomic_load(K.wg_totals + lane + 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-    const unsigned long long i0 = wave_inclusive_scan(t0, lane);
-    const unsigned long long i1 = wave_inclusive_scan(t1, lane) + __shfl(i0, 63);
-    const unsigned long long grand = __shfl(i1, 63);
-    auto incl_of = [&](unsigned w) { return w < 64u ? __shfl(i0, (int)w) : __shfl(i1, (int)(w - 64u)); };   // w wave-uniform
-    const unsigned long long before = g == 0u ? 0ull : incl_of(g - 1u);
-    Acc acc = {};
-    if (W.first != 0u) acc = *K.d_acc;   // the launches before this one; rewritten by wave 0 at the very end
-    // which path supplies record number max_vpl, if any of this launch does
-    const unsigned need = K.max_vpl - acc.size;   // records still missing (> 0: a complete set ends the call)
-    const unsigned long long m0 = __ballot(lane < n_w && (unsigned)(i0 & 0xFFFFFFFFull) >= need);
-    const unsigned long long m1 = __ballot(lane + 64u < n_w && (unsigned)(i1 & 0xFFFFFFFFull) >= need);
-    const bool done = (m0 | m1) != 0ull;
-    float inv = 0.0f;
-    if (done) {
-        const unsigned gd = m0 ? (unsigned)__ffsll((long long)m0) - 1u : 63u + (unsigned)__ffsll((long long)m1);
-        const unsigned need_in = need - (unsigned)((gd == 0u ? 0ull : incl_of(gd - 1u)) & 0xFFFFFFFFull);
-        const unsigned long long d0 = __hip_atomic_load(K.wg_masks + 2u * gd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long d1 = __hip_atomic_load(K.wg_masks + 2u * gd + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long le = lane == 63u ? ~0ull : (1ull << (lane + 1u)) - 1ull;
-        const unsigned pref = (unsigned)__popcll(d0 & le) + 2u * (unsigned)__popcll(d1 & le);
-        const unsigned long long md = __ballot(pref >= need_in);
-        acc.done = 1u;
-        acc.n_paths = W.first + gd * L + (unsigned)__ffsll((long long)md);   // path index + 1 (PhotonTracer.cpp:115, :159, :180)
-        inv = 1.0f / (float)(int)acc.n_paths;   // LightArray.hpp:47
-    }
-    // The usual case, a set that this first launch completes: every wave knows 1 / n_paths and writes its records,
-    // scaled, to the page-locked host set itself (the staging is uncached on the device side, so records of
-    // different waves may share a line).  Otherwise the records collect in device memory over the launches and the
-    // last wave of the launch that completes the set scales and copies them.
-    const bool direct = acc.done && W.first == 0u;
-    {
-        const unsigned long long excl = before + incl - mine;
-        const unsigned base = acc.size + (unsigned)(excl & 0xFFFFFFFFull);
-        const unsigned new_id = acc.contrib + (unsigned)(excl >> 32);
-        for (unsigned j = 0; j < cnt; ++j) {
-            const unsigned pos = base + j;
-            if (pos >= K.max_vpl) break;
-            VplRec r = W.slots[(size_t)i * kGiBounces + j];
-            r.w[11] = new_id;   // LightArray::normalizeIntensity's renumbering: ids count the contributing paths
-            if (direct) {   // intensity / n_paths (PointLight.h:68), straight into the host's set
-#pragma unroll
-                for (unsigned c = 4u; c < 7u; ++c) r.w[c] = __float_as_uint(__uint_as_float(r.w[c]) * inv);
-                K.h_out[pos] = r;
-            } else {
-                K.d_out[pos] = r;
-            }
-        }
-    }
-    if (timed_out && lane == 0u) *W.error = 2u;
-    STAMP();
-    // The records are in place.  Every wave checks out (what it wrote to the host is out, system scope, before its
-    // ticket); the last one writes the totals and, for a set that took several launches, scales and copies it.
-    __threadfence_system();
+    __threadfence_system();   // records and count are out (system scope) before the wave checks in
     unsigned ticket = 0u;
-    if (lane == 0u) ticket = atomicAdd(K.barrier, 1u);
+    if (lane == 0u) ticket = atomicAdd(K.arrivals, 1u);
     ticket = __shfl(ticket, 0);
-    if (ticket != K.epoch + 2u * n_w - 1u) return;
-    __threadfence();
-    acc.size += (unsigned)(grand & 0xFFFFFFFFull);
-    acc.contrib += (unsigned)(grand >> 32);
-    acc.error = __hip_atomic_load(W.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (acc.done && !acc.error && !direct) {
-        const unsigned* src = reinterpret_cast<const unsigned*>(K.d_out);
-        unsigned* dst = reinterpret_cast<unsigned*>(K.h_out);
-        const unsigned n_words = K.max_vpl * 24u;
-        for (unsigned k0 = 0; k0 < n_words; k0 += 64u * 8u) {
-            unsigned w[8];
-#pragma unroll
-            for (unsigned u = 0; u < 8u; ++u) {   // eight independent loads in flight per lane
-                const unsigned k = k0 + u * 64u + lane;
-                w[u] = k < n_words ? src[k] : 0u;
-            }
-#pragma unroll
-            for (unsigned u = 0; u < 8u; ++u) {
-                const unsigned k = k0 + u * 64u + lane;
-                const unsigned c = k % 24u;
-                if (c >= 4u && c < 7u) w[u] = __float_as_uint(__uint_as_float(w[u]) * inv);   // intensity (PointLight.h:68)
-                if (k < n_words) dst[k] = w[u];
-            }
-        }
-    }
+    if (ticket != K.epoch + gridDim.x - 1u) return;
+    __threadfence();   // what the others wrote (the error word) is seen behind the last check-in
+    STAMP();
     if (lane == 0u) {
-        *K.d_acc = acc;
-        *K.h_acc = acc;
+        *K.h_err = __hip_atomic_load(W.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *W.error = 0u;
     }
-    STAMP();
-    // the host waits for this word rather than for the launch to retire: everything the wave wrote to host memory is
-    // out (system scope) before the word is
     __threadfence_system();
     __builtin_amdgcn_wave_barrier();
     if (lane == 0u) __hip_atomic_store(K.h_flag, K.token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    STAMP();
 }
 
 // walk_lean over an explicit ray batch, one ray per lane, 64 per workgroup: the cross-check of the lean walk against
@@ -663,12 +552,10 @@ extern "C" int gigl_photon_trace_batch(const gigl_scene* s, const gigl_fog* fog,
     const int small_opt = option_photon_small();
     const bool small = (unsigned)max_vpl_count <= kSmallMaxVpls && P <= kSmallMaxPaths &&
                        (small_opt == 1 || (small_opt < 0 && paths_per_batch == 0));
-    // its spill area: one 64-lane workgroup per 64 paths = P / 256 of the batched launches' 256-lane workgroups
-    const size_t o_tws = take(trace_workspace_bytes(std::max<unsigned>(trace_blocks, 128u * 64u / 256u)));   // the one-launch route: at most 128 waves
-    // the barrier counter (64 B), per-wave work counters (2 words x 128 waves, from +64), per-wave totals (from
-    // +2048) and per-wave count masks (from +3072)
-    const size_t o_small = take(3072 + 128 * 16);
-    static_assert(kSmallMaxPaths == 128 * 32, "at most 128 waves of 32 paths per launch");
+    // its spill area: packed columns, one per path (photon_small_kernel), kSmallMaxPaths and a wave's worth at most
+    const size_t o_tws = take(trace_workspace_bytes(std::max<unsigned>(trace_blocks, kSmallMaxPaths / 256u + 1u)));
+    // the check-in counter (first 256 B) and one word per path of a launch: the records it holds
+    const size_t o_small = take(256 + (size_t)(kSmallMaxPaths + 64) * 4);
     // the workspace and the stream belong to the scene and are kept between calls (a 150-VPL set is a
     // dozen short launches: allocating per call would cost as much as the walk); calls on one scene serialise
     gigl_scene* ms = const_cast<gigl_scene*>(s);
@@ -716,12 +603,16 @@ extern "C" int gigl_photon_trace_batch(const gigl_scene* s, const gigl_fog* fog,
         Acc* d_acc = (Acc*)(ws + o_acc);
         VplRec* d_out = (VplRec*)(ws + o_out);
         if (small) {
-            constexpr size_t h_bytes = (size_t)kSmallMaxVpls * sizeof(VplRec) + 256;
+            // page-locked, device-mapped, coherent (uncached on the device side): the paths' record slots, their
+            // counts, and the error and flag words — the host reads them as soon as the flag says every wave is done
+            constexpr size_t h_slots_bytes = (size_t)kSmallMaxPaths * kGiBounces * sizeof(VplRec);
+            constexpr size_t h_cnt_at = h_slots_bytes, h_words_at = h_cnt_at + (size_t)kSmallMaxPaths * 4;
+            constexpr size_t h_bytes = h_words_at + 256;
             if (!ms->photon_h) {
-                // coherent: the host reads the set as soon as the kernel's flag says it is complete, not at the end of the launch
                 HIP_TRY(hipHostMalloc(&ms->photon_h, h_bytes, hipHostMallocMapped | hipHostMallocCoherent));
                 HIP_TRY(hipHostGetDevicePointer(&ms->photon_h_dev, ms->photon_h, 0));
             }
+            W.slots = (VplRec*)ms->photon_h_dev;   // path_bounce writes its records straight to the host
             TraceParams Q = {};
             scene_trace_params(s, Q);
             Q.o_tmin = W.o_tmin; Q.d_tmax = W.d_tmax;
@@ -731,18 +622,13 @@ extern "C" int gigl_photon_trace_batch(const gigl_scene* s, const gigl_fog* fog,
             // lanes would end it after every step): -3 %
             Q.refill_thresh = 24; Q.chunk = 64u; Q.guided = 0u; Q.t_exit = 1;
             SmallParams K = {};
-            K.max_vpl = (unsigned)max_vpl_count;
-            K.d_out = d_out;
-            K.h_out = (VplRec*)ms->photon_h_dev;
-            K.d_acc = d_acc;
-            K.h_acc = (Acc*)((char*)ms->photon_h_dev + (size_t)kSmallMaxVpls * sizeof(VplRec));
-            K.barrier = (unsigned*)(ws + o_small);
-            K.wg_masks = (unsigned long long*)(ws + o_small + 3072);
-            K.counters = (unsigned*)(ws + o_small + 64);
-            K.wg_totals = (unsigned long long*)(ws + o_small + 2048);
-            // the barrier counter only grows (every launch adds two arrivals per wave; the host keeps count); a new
+            K.h_cnt = (unsigned*)((char*)ms->photon_h_dev + h_cnt_at);
+            K.h_err = (unsigned*)((char*)ms->photon_h_dev + h_words_at);
+            K.h_flag = (unsigned*)((char*)ms->photon_h_dev + h_words_at + 128);
+            K.arrivals = (unsigned*)(ws + o_small);
+            // the check-in counter only grows (every launch adds one arrival per wave; the host keeps count); a new
             // workspace, or one whose layout moved with another block size, starts from zero, and so does the error
-            // word, which wave 0 clears again after reading it
+            // word, which the last wave clears again after reading it
             if (ms->photon_small_at != ws + o_small) {
                 HIP_TRY(hipMemsetAsync(ws + o_small, 0, 64, st));
                 HIP_TRY(hipMemsetAsync(W.error, 0, 4, st));
@@ -750,35 +636,45 @@ extern "C" int gigl_photon_trace_batch(const gigl_scene* s, const gigl_fog* fog,
                 ms->photon_epoch = 0u;
             }
             // A launch walks what the set is expected to need and a quarter more (the workspace stays sized for P): a
-            // set of the reference's size needs about 3 paths per record, so 640 paths in 80 waves rather than 1,024
-            // in 128 — the barrier waits for the slowest wave of fewer.  The estimate follows the sets made so far.
+            // set of the reference's size needs about 3 paths per record, so 640 paths rather than 1,024.  The estimate
+            // follows the sets made so far.
             const unsigned Ps = std::min<unsigned>(P, std::max<unsigned>(256u,
                 (unsigned)(1.25f * ms->photon_rate * (float)max_vpl_count + 127.0f) & ~127u));
-            K.lanes = Ps <= 512u ? 4u : (Ps <= 1024u ? 8u : (Ps <= 2048u ? 16u : 32u));   // at most 128 waves per launch
+            // Few paths per wave: a wave takes, at every phase, as long as the longest of its paths, and no wave waits
+            // for another.  Measured on the 150-VPL set (640 paths): 1 / 2 / 4 / 8 paths per wave 0.088 / 0.082 / 0.083 /
+            // 0.084 ms — beyond some 400 waves the slowest ones get slower (two and three waves to a CU), so the
+            // launch takes the fewest paths per wave that keep it under 384 waves.
+            K.lanes = 1u;
+            while ((Ps + K.lanes - 1u) / K.lanes > 384u) K.lanes *= 2u;
+            if (const char* e = getenv("GIGL_PHOTON_LANES")) { const unsigned l = (unsigned)atoi(e); if (l && l <= 32u && (l & (l - 1u)) == 0u) K.lanes = l; }
 #if GIGL_PHOTON_STAMPS
-            static unsigned long long* h_stamps = nullptr;
+            // stamps go to device memory and are copied back after the launch (written to host memory they queue up
+            // behind one another on the way out, and the phases' fences wait for them)
             static unsigned long long* d_stamps = nullptr;
-            if (!h_stamps) {
-                HIP_TRY(hipHostMalloc((void**)&h_stamps, 128 * 16 * 8, hipHostMallocMapped | hipHostMallocCoherent));
-                HIP_TRY(hipHostGetDevicePointer((void**)&d_stamps, h_stamps, 0));
-            }
-            std::memset(h_stamps, 0, 128 * 16 * 8);
+            static std::vector<unsigned long long> h_stamps_v;
+            if (!d_stamps) HIP_TRY(hipMalloc((void**)&d_stamps, (size_t)kSmallMaxPaths * 16 * 8));
+            h_stamps_v.assign((size_t)kSmallMaxPaths * 16, 0ull);
+            unsigned long long* h_stamps = h_stamps_v.data();
+            HIP_TRY(hipMemsetAsync(d_stamps, 0, (size_t)kSmallMaxPaths * 16 * 8, st));
             K.stamps = d_stamps;
 #endif
             auto kern = s->triples ? photon_small_kernel<true> : photon_small_kernel<false>;
-            const Acc* h_acc = (const Acc*)((char*)ms->photon_h + (size_t)kSmallMaxVpls * sizeof(VplRec));
-            volatile unsigned* h_flag = (volatile unsigned*)((char*)ms->photon_h + (size_t)kSmallMaxVpls * sizeof(VplRec) + 128);
-            K.h_flag = (unsigned*)((char*)ms->photon_h_dev + (size_t)kSmallMaxVpls * sizeof(VplRec) + 128);
+            const VplRec* h_slots = (const VplRec*)ms->photon_h;
+            unsigned* h_cnt = (unsigned*)((char*)ms->photon_h + h_cnt_at);
+            const volatile unsigned* h_err = (const volatile unsigned*)((char*)ms->photon_h + h_words_at);
+            volatile unsigned* h_flag = (volatile unsigned*)((char*)ms->photon_h + h_words_at + 128);
+            VplRec* out = (VplRec*)vpls_out;
             uint64_t first = 0;
             while (first < path_limit) {
                 const unsigned nb = (unsigned)std::min<uint64_t>(Ps, path_limit - first);
                 const unsigned grid = (nb + K.lanes - 1u) / K.lanes;
                 W.first = (unsigned)first; W.n = nb;
-                Q.spill_stride = grid * 64u;
+                Q.spill_stride = grid * K.lanes;   // packed columns (photon_small_kernel)
                 K.epoch = ms->photon_epoch;
-                ms->photon_epoch += 2u * grid;
+                ms->photon_epoch += grid;
                 K.token = ms->photon_epoch | 0x80000000u;   // never 0, new with every launch
                 *h_flag = 0u;
+                std::memset(h_cnt, 0, (size_t)grid * K.lanes * 4);   // only the paths that hold records write their count
 #if GIGL_PHOTON_STAMPS
                 const auto tq0 = std::chrono::steady_clock::now();
 #endif
@@ -805,9 +701,10 @@ extern "C" int gigl_photon_trace_batch(const gigl_scene* s, const gigl_fog* fog,
 #if GIGL_PHOTON_STAMPS
                 if (getenv("GIGL_PHOTON_TIMING")) {
                     (void)hipStreamSynchronize(st);
+                    (void)hipMemcpy(h_stamps, d_stamps, (size_t)kSmallMaxPaths * 16 * 8, hipMemcpyDeviceToHost);
                     // per stamp: latest wave, relative to the earliest start; names of the intervals
                     static const char* nm[] = {"start", "path_start", "walk1", "bounce1", "walk2", "bounce2", "walk3", "bounce3",
-                                               "scan", "barrier", "place", "last wave: host copy"};
+                                               "count out", "last wave: checked in", "flag", "-"};
                     unsigned long long t0 = ~0ull;
                     for (unsigned w = 0; w < grid; ++w) t0 = std::min(t0, h_stamps[w * 16]);
                     fprintf(stderr, "[stamps] %u waves;", grid);
@@ -832,12 +729,24 @@ extern "C" int gigl_photon_trace_batch(const gigl_scene* s, const gigl_fog* fog,
                     ms->photon_small_at = nullptr;   // the counter is no longer where the host thinks it is
                     return fail(GIGL_ERR_HIP, std::string("photon_small_kernel: ") + hipGetErrorString(le));
                 }
-                std::memcpy(&acc, h_acc, sizeof(Acc));
-                if (acc.error == 2u) {
-                    ms->photon_small_at = nullptr;
-                    return fail(GIGL_ERR_HIP, "photon_small_kernel: the waves of the launch did not all arrive at its barrier");
+                if (*h_err) return fail(GIGL_ERR_INVALID, "a hit triangle names a material beyond n_mat");
+                // The ordered gather (vpl_gather_kernel's), on the host: the paths in order, every record to its place;
+                // the path that supplies record number max_vpl_count is the last one the serial loop counts
+                // (PhotonTracer.cpp:115, :159, :180); ids count the contributing paths (LightArray.hpp:46-66).
+                for (unsigned p = 0; p < nb && !acc.done; ++p) {
+                    const unsigned c = h_cnt[p];
+                    if (!c) continue;
+                    for (unsigned j = 0; j < c && !acc.done; ++j) {
+                        VplRec& r = out[acc.size];
+                        r = h_slots[(size_t)p * kGiBounces + j];
+                        r.w[11] = acc.contrib;
+                        if (++acc.size == (unsigned)max_vpl_count) {
+                            acc.done = 1u;
+                            acc.n_paths = (unsigned)first + p + 1u;
+                        }
+                    }
+                    ++acc.contrib;
                 }
-                if (acc.error) return fail(GIGL_ERR_INVALID, "a hit triangle names a material beyond n_mat");
                 if (acc.done) break;
                 first += nb;
             }
@@ -846,7 +755,16 @@ extern "C" int gigl_photon_trace_batch(const gigl_scene* s, const gigl_fog* fog,
                 if (n_paths_out) *n_paths_out = (uint32_t)path_limit;
                 return GIGL_OK;
             }
-            std::memcpy(vpls_out, ms->photon_h, (size_t)max_vpl_count * sizeof(VplRec));
+            {   // LightArray::normalizeIntensity, LightArray.hpp:47 and PointLight.h:68: intensity / n_paths
+                const float inv = 1.0f / (float)(int)acc.n_paths;
+                for (int v = 0; v < max_vpl_count; ++v)
+                    for (int c = 4; c < 7; ++c) {
+                        float f;
+                        std::memcpy(&f, &out[v].w[c], 4);
+                        f = f * inv;
+                        std::memcpy(&out[v].w[c], &f, 4);
+                    }
+            }
             ms->photon_rate = std::max(0.5f, 0.5f * ms->photon_rate + 0.5f * (float)acc.n_paths / (float)max_vpl_count);
             *n_vpls_out = max_vpl_count;
             if (n_paths_out) *n_paths_out = acc.n_paths;
