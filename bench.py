@@ -764,13 +764,14 @@ def vpl_config(args, torch, rt, S, device, ci=None):
                       "baseline_config": "configs[0]", "vpls": n_vpls, "paths_per_set": paths / args.steps,
                       "device_layout": cs.layout(), "setup_s": round(setup_s, 1), "commit": git_head()},
            "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-                        "kernel": ("photon_small_kernel (the whole set in one launch: one wave per 4-32 paths walks the tree "
-                                   "itself, one grid barrier for the ordered gather, every wave writes its records to the "
-                                   "host's set)") if n_vpls <= 1024 else
-                                  "photon_start/bounce kernels + trace_kernel per bounce",
-                        "note": "latency bound at this size: a set is the dependent chain of the slowest wave (three tree walks and "
-                                "three path steps, ~63 us; the average wave takes 36), ~10 us behind the barrier and ~10 us "
-                                "of launch and flag latency (profiles/r03_vpl_stamps.txt); no bandwidth figure applies"},
+                        "kernel": ("photon_small_kernel (the whole set in one launch: one wave per 1-16 paths walks the tree "
+                                   "itself and writes its records to page-locked host memory; no barrier, the last wave to "
+                                   "check in raises a flag the call polls; ordered gather and scaling on the host)")
+                                  if n_vpls <= 1024 else "photon_start/bounce kernels + trace_kernel per bounce",
+                        "note": "latency bound at this size: a set is the dependent chain of its slowest path (three tree "
+                                "walks and three path steps, some 8,000 instructions of a lone wave: 55-58 us; the average "
+                                "wave takes 20) plus launch and flag latency (profiles/r03_vpl_stamps.txt); no bandwidth "
+                                "figure applies"},
            "cpu_baseline": cpu, "parity": parity, "host": hinfo}
     if own_ci:
         fog.close()
