@@ -554,8 +554,8 @@ extern "C" int gigl_photon_trace_batch(const gigl_scene* s, const gigl_fog* fog,
                        (small_opt == 1 || (small_opt < 0 && paths_per_batch == 0));
     // its spill area: packed columns, one per path (photon_small_kernel), kSmallMaxPaths and a wave's worth at most
     const size_t o_tws = take(trace_workspace_bytes(std::max<unsigned>(trace_blocks, kSmallMaxPaths / 256u + 1u)));
-    // the check-in counter (first 256 B) and one word per path of a launch: the records it holds
-    const size_t o_small = take(256 + (size_t)(kSmallMaxPaths + 64) * 4);
+    // the check-in counter of the one-launch route
+    const size_t o_small = take(256);
     // the workspace and the stream belong to the scene and are kept between calls (a 150-VPL set is a
     // dozen short launches: allocating per call would cost as much as the walk); calls on one scene serialise
     gigl_scene* ms = const_cast<gigl_scene*>(s);
@@ -685,7 +685,7 @@ extern "C" int gigl_photon_trace_batch(const gigl_scene* s, const gigl_fog* fog,
 #endif
                 // The last wave raises the flag when the set and the totals are in host memory: the call returns then,
                 // some 20 us before the runtime would report the launch retired.  Every few thousand polls the stream is
-                // asked whether it failed or finished without the flag (a fault, a barrier that gave up).
+                // asked whether it failed or finished without the flag (a fault).
                 if (le == hipSuccess) {
                     for (unsigned spins = 1u;; ++spins) {
                         if (__atomic_load_n((const unsigned*)h_flag, __ATOMIC_ACQUIRE) == K.token) break;
