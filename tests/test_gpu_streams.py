@@ -191,3 +191,28 @@ def test_lean_walk_equals_the_shipped_kernel(s64):
                                       torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy(), s64["want"])
+
+
+def test_lean_walk_entry_point_rejects_what_it_cannot_walk(cornell):
+    """gigl_debug_trace_closest_lean_device reads triple records only; an empty batch is a no-op; NULL pointers and a
+    host-only scene are errors, not faults."""
+    import torch
+    rt.set_option("layout", 1)
+    try:
+        pairs = rt.Scene(cornell["verts"], cornell["tris"], device=0, **S.KD_PARAMS)
+    finally:
+        rt.set_option("layout", 2)
+    o = torch.zeros((64, 4), device="cuda"); d = torch.ones((64, 4), device="cuda")
+    h = torch.zeros((64, 4), dtype=torch.int32, device="cuda")
+    with pytest.raises(rt.GiglError):
+        pairs.debug_trace_closest_lean_device(o.data_ptr(), d.data_ptr(), 64, h.data_ptr(), 0)
+    pairs.close()
+    g = rt.Scene(cornell["verts"], cornell["tris"], device=0, **S.KD_PARAMS)
+    g.debug_trace_closest_lean_device(0, 0, 0, 0, 0)                      # n = 0: nothing to do
+    with pytest.raises(rt.GiglError):
+        g.debug_trace_closest_lean_device(0, d.data_ptr(), 64, h.data_ptr(), 0)
+    g.close()
+    host_only = rt.Scene(cornell["verts"], cornell["tris"], device=-1, **S.KD_PARAMS)
+    with pytest.raises(rt.GiglError):
+        host_only.debug_trace_closest_lean_device(o.data_ptr(), d.data_ptr(), 64, h.data_ptr(), 0)
+    host_only.close()
