@@ -178,7 +178,7 @@ def test_instrumented_build_counts_and_timeline(s64):
     assert n // 32 < started < n // 8, (started, n)            # a sixteenth of the waves, give or take
     assert rounds > 0 and lanes <= 64 * rounds
     used = np.nonzero(tl[1])[0]
-    assert used[0] == 0 and used[-1] < 1023                    # starts in the first bucket, ends long before the wrap
+    assert used[0] <= 1 and used[-1] < 1023                    # starts with the first wave (give or take a bucket's edge), ends long before the wrap
 
 
 def test_lean_walk_equals_the_shipped_kernel(s64):
